@@ -1,0 +1,89 @@
+"""ctypes binding of libevoworld_hip.so (the C ABI in include/evoworld_hip.h).
+
+The library is built in-tree by `make -C evoworld_amd/csrc` (or __graft_entry__.build()).  Loading fails
+loudly -- there is no CPU / PyTorch fallback for the product path.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libevoworld_hip.so")
+ABI_VERSION = 1
+
+# every symbol declared in include/evoworld_hip.h
+SYMBOLS = [
+    "ew_abi_version", "ew_last_error", "ew_gemm_f16", "ew_groupnorm_stats_f16", "ew_groupnorm_apply_f16",
+    "ew_layernorm_f16", "ew_attn_spatial_f16", "ew_attn_temporal_f16", "ew_nchw_f32_to_nhwc_f16",
+    "ew_nhwc_f16_to_nchw_f32", "ew_euler_cfg_step", "ew_plucker_embed", "ew_cube2equi_gather",
+    "ew_depth_unproject", "ew_splat_cubemap", "ew_splat_resolve", "ew_equi2pers",
+]
+
+
+class GemmArgs(ctypes.Structure):
+    """struct ew_gemm_args (include/evoworld_hip.h)."""
+    _fields_ = [
+        ("a", c_void_p), ("a2", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("rowbias", c_void_p),
+        ("r1", c_void_p), ("r2", c_void_p), ("out", c_void_p), ("zero_page", c_void_p),
+        ("M", c_int), ("N", c_int), ("c1", c_int), ("c2", c_int), ("lda", c_int), ("lda2", c_int),
+        ("ld_out", c_int), ("ld_r1", c_int), ("ld_r2", c_int), ("ld_rowbias", c_int), ("mode", c_int),
+        ("n_img", c_int), ("h_in", c_int), ("w_in", c_int), ("h_out", c_int), ("w_out", c_int),
+        ("stride", c_int), ("upsample", c_int), ("tB", c_int), ("tT", c_int), ("tP", c_int),
+        ("rows_per_group", c_int), ("act", c_int), ("c_acc", c_float), ("c_r1", c_float), ("c_r2", c_float),
+    ]
+
+
+_lib = None
+
+
+class EvoWorldHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise (never fall back) if it is missing or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EvoWorldHipError(
+            f"{LIB_PATH} not found: build it with `make -C evoworld_amd/csrc` (hipcc --offload-arch=gfx950). "
+            "evoworld_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for s in SYMBOLS:
+        if not hasattr(lib, s):
+            raise EvoWorldHipError(f"{LIB_PATH} does not export {s}")
+    lib.ew_last_error.restype = c_char_p
+    lib.ew_abi_version.restype = c_int
+    if lib.ew_abi_version() != ABI_VERSION:
+        raise EvoWorldHipError(f"ABI mismatch: library {lib.ew_abi_version()} != binding {ABI_VERSION}")
+    P, I, F, LL = c_void_p, c_int, c_float, c_longlong
+    sig = {
+        "ew_gemm_f16": [ctypes.POINTER(GemmArgs), P],
+        "ew_groupnorm_stats_f16": [P, P, I, I, I, I, I, I, P],
+        "ew_groupnorm_apply_f16": [P, P, P, P, P, I, I, I, I, I, I, F, I, P],
+        "ew_layernorm_f16": [P, P, I, P, P, P, P, I, I, F, P],
+        "ew_attn_spatial_f16": [P, P, P, P, I, I, I, I, LL, I, F, P],
+        "ew_attn_temporal_f16": [P, P, P, P, I, I, I, I, I, I, F, P],
+        "ew_nchw_f32_to_nhwc_f16": [P, P, I, I, I, I, I, I, F, P],
+        "ew_nhwc_f16_to_nchw_f32": [P, P, I, I, I, I, I, P],
+        "ew_euler_cfg_step": [P, I, P, P, F, F, P, I, I, I, I, P],
+        "ew_plucker_embed": [P, P, P, I, I, I, P],
+        "ew_cube2equi_gather": [P, P, P, I, I, I, I, P],
+        "ew_depth_unproject": [P, P, P, P, I, I, I, P],
+        "ew_splat_cubemap": [P, c_size_t, P, P, I, I, F, F, F, F, F, P],
+        "ew_splat_resolve": [P, P, P, I, I, P],
+        "ew_equi2pers": [P, P, P, I, I, I, I, I, F, P],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().ew_last_error()
+        raise EvoWorldHipError(f"{what} failed ({status}): {msg.decode() if msg else ''}")

@@ -1,0 +1,294 @@
+// attention.hip -- self-attention cores of the spatio-temporal transformer blocks (gfx950, head_dim 64).
+//
+//  * ew_attn_spatial_f16: flash-style tiled softmax(QK^T)V over S = H*W tokens per frame (S up to 9216 at
+//    config 2, 32768 at config 5).  MFMA 32x32x16 f16.  The score tile is computed SWAPPED, S^T = K Q^T, so
+//    that every lane owns ONE query column: the online-softmax max/sum are lane-local (one cross-half
+//    exchange per tile) and the O^T accumulator rescale is a per-lane scalar.  P feeds the second MFMA
+//    straight from registers: the key order inside each 16-key MFMA step is whatever the S^T fragment
+//    layout yields, and the V^T tile is written to LDS in that same order, so no cross-lane shuffle of P
+//    is needed.  V arrives TRANSPOSED from the projection GEMM (swapped-operand ew_gemm_f16), so the PV
+//    A-operand is a plain ds_read_b128.
+//  * ew_attn_temporal_f16: attention over the frame axis (T<=32) for every (batch, pixel, head).  It is
+//    HBM-bound (0.13 TFLOP per forward vs ~1.2 GB of q/k/v per call at level 0), so it runs on the VALU
+//    (v_dot2 for QK^T, fp32 FMA for PV) with K/V rows broadcast from LDS; the [B*T,S,C]<->[B*S,T,C] regroup
+//    of the reference is pure addressing.
+// Reference call sites: diffusers AttnProcessor2_0 / F.scaled_dot_product_attention inside
+// BasicTransformerBlock.attn1 and TemporalBasicTransformerBlock.attn1, instantiated through
+// evoworld/trainer/unet_plucker.py:13,161-233.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
+
+__global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+                                                               const f16* __restrict__ vt, f16* __restrict__ o, int S,
+                                                               int heads, int ld_qk, long long ld_vt, int ld_o, float sl2,
+                                                               int n_qtiles) {
+    __shared__ __attribute__((aligned(16))) char smem[16384];  // K tile [64 keys][64 d] | V^T tile [64 d][64 keys]
+    char* const kl = smem;
+    char* const vl = smem + 8192;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, lh = lane >> 5;
+
+    // XCD-aware remap: all q-tiles of a (sequence, head) pair run on one XCD so K/V stay in that L2
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int qq = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+    }
+    const int pair = bid / n_qtiles, qtile = bid - pair * n_qtiles;
+    const int seq = pair / heads, head = pair - seq * heads;
+    const long long tok0 = (long long)seq * S;
+
+    // Q fragments (B operand): query = q0 + lq, d = 16*s + 8*lh + e
+    const int q_idx = qtile * 128 + wave * 32 + lq;
+    const int q_ld = q_idx < S ? q_idx : S - 1;
+    f16x8 qf[4];
+    {
+        const f16* qp = q + (tok0 + q_ld) * ld_qk + head * 64 + lh * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *(const f16x8*)(qp + s * 16);
+    }
+
+    // staging geometry
+    const int srow = tid >> 2, sc = tid & 3;
+    const f16* kbase = k + head * 64 + sc * 16;
+    const f16* vbase = vt + (long long)(head * 64 + srow) * ld_vt + tok0 + sc * 16;
+    const int k_w0 = srow * 128 + (((sc * 2) ^ swz(srow)) << 4), k_w1 = srow * 128 + (((sc * 2 + 1) ^ swz(srow)) << 4);
+
+    f16x8 kr0, kr1, vr0, vr1;
+    auto load_tile = [&](int key0) {
+        int kr = key0 + srow;
+        kr = kr < S ? kr : S - 1;
+        const f16* kp = kbase + (tok0 + kr) * ld_qk;
+        kr0 = *(const f16x8*)kp;
+        kr1 = *(const f16x8*)(kp + 8);
+        const int c = key0 + sc * 16;
+        const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        vr0 = c < S ? *(const f16x8*)(vbase + key0) : z;
+        vr1 = c + 8 < S ? *(const f16x8*)(vbase + key0 + 8) : z;
+    };
+    auto write_tile = [&]() {
+        *(f16x8*)(kl + k_w0) = kr0;
+        *(f16x8*)(kl + k_w1) = kr1;
+        // 16-key group -> slot A = keys {0..3, 8..11}, slot B = keys {4..7, 12..15}
+        const f16x8 sa = {vr0[0], vr0[1], vr0[2], vr0[3], vr1[0], vr1[1], vr1[2], vr1[3]};
+        const f16x8 sb = {vr0[4], vr0[5], vr0[6], vr0[7], vr1[4], vr1[5], vr1[6], vr1[7]};
+        *(f16x8*)(vl + k_w0) = sa;   // same (row, slot) geometry as the K tile: row = srow (d), slots 2*sc, 2*sc+1
+        *(f16x8*)(vl + k_w1) = sb;
+    };
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // fragment read offsets
+    const int fr_sw = swz(lq);  // rows lq and lq+32 have the same swizzle: ((r+32)^((r+32)>>3))&7 == (r^(r>>3)^4)&7 -> differs
+    const int fr_sw1 = swz(lq + 32);
+
+    const int nt = (S + 63) / 64;
+    load_tile(0);
+    write_tile();
+    __syncthreads();
+    for (int j = 0; j < nt; ++j) {
+        const int key0 = j * 64;
+        if (j + 1 < nt) load_tile(key0 + 64);
+
+        // ---- S^T = K Q^T : two 32-key blocks ----
+        f32x16 sacc[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[blk][i] = 0.f;
+            const int row = blk * 32 + lq;
+            const int sw = blk ? fr_sw1 : fr_sw;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f16x8 kf = *(const f16x8*)(kl + row * 128 + (((2 * s + lh) ^ sw) << 4));
+                sacc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[blk], 0, 0, 0);
+            }
+        }
+        // ---- mask the ragged last tile ----
+        if (key0 + 64 > S) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= S) sacc[blk][r] = -INFINITY;
+                }
+        }
+        // ---- online softmax (this lane: one query, 32 of the 64 keys; partner lane^32 has the rest) ----
+        float tmax = sacc[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sacc[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[1][r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax * sl2);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        f16x8 pf[4];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(sacc[blk][r] * sl2 - m_new);
+                psum += pv;
+                pf[blk * 2 + (r >> 3)][r & 7] = (f16)pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {       // 16-key group (MFMA k-step)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int row = db * 32 + lq;
+                const int sw = db ? fr_sw1 : fr_sw;
+                const f16x8 vf = *(const f16x8*)(vl + row * 128 + (((2 * g + lh) ^ sw) << 4));
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[g], oacc[db], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (j + 1 < nt) write_tile();
+        __syncthreads();
+    }
+    // ---- normalise + store: lane holds query q_idx, d = 32*db + 8*(r>>2) + 4*lh + (r&3) ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_idx < S) {
+        f16* op = o + (tok0 + q_idx) * ld_o + head * 64 + 4 * lh;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const f16x4 v = {(f16)(oacc[db][rq * 4 + 0] * inv), (f16)(oacc[db][rq * 4 + 1] * inv),
+                                 (f16)(oacc[db][rq * 4 + 2] * inv), (f16)(oacc[db][rq * 4 + 3] * inv)};
+                *(f16x4*)(op + db * 32 + rq * 8) = v;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// temporal attention: half-wave (32 lanes) per (batch, pixel, head) problem, lane = frame t
+// ---------------------------------------------------------------------------------------------
+typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+                                                            const f16* __restrict__ v, f16* __restrict__ o, int B, int T,
+                                                            int S, int heads, int ld, int ld_o, float scale,
+                                                            long long n_prob) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 2 * 2 * 32 * 128];  // [wave][prob][k|v][t][64 f16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, t = lane & 31;
+    const long long pid = ((long long)blockIdx.x * 4 + wave) * 2 + half;
+    const bool active = pid < n_prob;
+    const long long pc = active ? pid : n_prob - 1;
+    const int h = (int)(pc % heads);
+    const long long bs = pc / heads;
+    const int b = (int)(bs / S), s = (int)(bs - (long long)b * S);
+    const int tt = t < T ? t : T - 1;
+    const long long row = ((long long)b * T + tt) * S + s;
+    char* const kl = smem + ((wave * 2 + half) * 2 + 0) * 4096;
+    char* const vl = smem + ((wave * 2 + half) * 2 + 1) * 4096;
+
+    f16x8 qv[8];
+    {
+        const f16* qp = q + row * ld + h * 64;
+        const f16* kp = k + row * ld + h * 64;
+        const f16* vp = v + row * ld + h * 64;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            qv[i] = *(const f16x8*)(qp + i * 8);
+            *(f16x8*)(kl + t * 128 + i * 16) = *(const f16x8*)(kp + i * 8);
+            *(f16x8*)(vl + t * 128 + i * 16) = *(const f16x8*)(vp + i * 8);
+        }
+    }
+    __syncthreads();
+    float sc[32];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        float a = 0.f;
+        if (j < T) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f16x8 kv = *(const f16x8*)(kl + j * 128 + i * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const h2_t x = {(__fp16)qv[i][2 * e], (__fp16)qv[i][2 * e + 1]};
+                    const h2_t y = {(__fp16)kv[2 * e], (__fp16)kv[2 * e + 1]};
+                    a = __builtin_amdgcn_fdot2(x, y, a, false);
+                }
+            }
+            a *= scale;
+            mx = fmaxf(mx, a);
+        }
+        sc[j] = a;
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const float pj = j < T ? __expf(sc[j] - mx) : 0.f;
+        sc[j] = pj;
+        l += pj;
+    }
+    const float inv = 1.0f / l;
+    f16* op = o + row * ld_o + h * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            if (j < T) {
+                const f16x8 vv = *(const f16x8*)(vl + j * 128 + i * 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += sc[j] * (float)vv[e];
+            }
+        }
+        if (active && t < T) {
+            f16x8 ov;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = (f16)(acc[e] * inv);
+            *(f16x8*)(op + i * 8) = ov;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" ew_status ew_attn_spatial_f16(const void* q, const void* k, const void* vt, void* o, int n_seq, int S, int heads,
+                                         int ld_qk, long long ld_vt, int ld_o, float scale, void* stream) {
+    EW_REQUIRE(q && k && vt && o, "ew_attn_spatial_f16: null pointer");
+    EW_REQUIRE(n_seq > 0 && S > 0 && heads > 0, "ew_attn_spatial_f16: bad shape");
+    EW_REQUIRE(S % 8 == 0, "ew_attn_spatial_f16: S must be a multiple of 8 (S=%d)", S);
+    EW_REQUIRE(ld_qk % 8 == 0 && ld_vt % 8 == 0 && ld_o % 4 == 0, "ew_attn_spatial_f16: strides must be 16-byte aligned");
+    const int n_qtiles = ew_cdiv(S, 128);
+    const long long nblk = (long long)n_seq * heads * n_qtiles;
+    EW_REQUIRE(nblk < 0x7fffffffLL, "ew_attn_spatial_f16: grid too large");
+    hipLaunchKernelGGL(attn_spatial_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const f16*)q,
+                       (const f16*)k, (const f16*)vt, (f16*)o, S, heads, ld_qk, ld_vt, ld_o,
+                       scale * 1.4426950408889634f, n_qtiles);
+    return ew_check_launch("ew_attn_spatial_f16");
+}
+
+extern "C" ew_status ew_attn_temporal_f16(const void* q, const void* k, const void* v, void* o, int B, int T, int S,
+                                          int heads, int ld, int ld_o, float scale, void* stream) {
+    EW_REQUIRE(q && k && v && o, "ew_attn_temporal_f16: null pointer");
+    EW_REQUIRE(B > 0 && S > 0 && heads > 0 && T > 0 && T <= 32, "ew_attn_temporal_f16: need 0 < T <= 32 (T=%d)", T);
+    EW_REQUIRE(ld % 8 == 0 && ld_o % 8 == 0, "ew_attn_temporal_f16: strides must be 16-byte aligned");
+    const long long n_prob = (long long)B * S * heads;
+    const long long nblk = (n_prob + 7) / 8;
+    EW_REQUIRE(nblk < 0x7fffffffLL, "ew_attn_temporal_f16: grid too large");
+    hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const f16*)q,
+                       (const f16*)k, (const f16*)v, (f16*)o, B, T, S, heads, ld, ld_o, scale, n_prob);
+    return ew_check_launch("ew_attn_temporal_f16");
+}

@@ -1,0 +1,204 @@
+"""Thin tensor->pointer wrappers over the C ABI (include/evoworld_hip.h).  torch is used only for device
+memory and the current HIP stream; every op below is one hand-written HIP kernel launch.  No fallback."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import GemmArgs
+
+A_DENSE, A_CONV3X3, A_CONVT3 = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+
+_zero_pages = {}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _req(t, dtype, name):
+    if t.device.type != "cuda":
+        raise _lib.EvoWorldHipError(f"{name} must live on the GPU (got {t.device}); evoworld_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def zero_page(device):
+    key = str(device)
+    if key not in _zero_pages:
+        _zero_pages[key] = torch.zeros(4096, dtype=torch.float16, device=device)
+    return _zero_pages[key]
+
+
+def gemm(a, w, out, *, M, N, c1, lda, a2=None, c2=0, lda2=0, bias=None, rowbias=None, rows_per_group=1, ld_rowbias=None,
+         r1=None, ld_r1=0, r2=None, ld_r2=0, ld_out=None, mode=A_DENSE, conv=None, tconv=None, act=ACT_NONE,
+         c_acc=1.0, c_r1=1.0, c_r2=1.0):
+    """out = c_acc*act(A@W^T + bias + rowbias) + c_r1*r1 + c_r2*r2  (see ew_gemm_f16).
+    conv = (n_img, h_in, w_in, h_out, w_out, stride, upsample); tconv = (B, T, P)."""
+    lib = _lib.load()
+    g = GemmArgs()
+    g.a, g.a2, g.w, g.bias, g.rowbias = _ptr(a), _ptr(a2), _ptr(w), _ptr(bias), _ptr(rowbias)
+    g.r1, g.r2, g.out, g.zero_page = _ptr(r1), _ptr(r2), _ptr(out), _ptr(zero_page(a.device))
+    g.M, g.N, g.c1, g.c2, g.lda, g.lda2 = M, N, c1, c2, lda, lda2
+    n_out = N // 2 if act == ACT_GEGLU else N
+    g.ld_out = ld_out if ld_out is not None else n_out
+    g.ld_r1, g.ld_r2, g.mode = ld_r1, ld_r2, mode
+    g.ld_rowbias = ld_rowbias if ld_rowbias is not None else N
+    if conv is not None:
+        g.n_img, g.h_in, g.w_in, g.h_out, g.w_out, g.stride, g.upsample = conv
+    if tconv is not None:
+        g.tB, g.tT, g.tP = tconv
+    g.rows_per_group, g.act = rows_per_group, act
+    g.c_acc, g.c_r1, g.c_r2 = c_acc, c_r1, c_r2
+    _lib.check(lib.ew_gemm_f16(ctypes.byref(g), _stream()), "ew_gemm_f16")
+    return out
+
+
+def linear(x, w, bias=None, out=None, **kw):
+    """x [M,K] fp16 (row stride = K), w [N,K] fp16 -> [M,N]."""
+    _req(x, torch.float16, "x"); _req(w, torch.float16, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    act = kw.get("act", ACT_NONE)
+    if out is None:
+        out = torch.empty(M, N // 2 if act == ACT_GEGLU else N, dtype=torch.float16, device=x.device)
+    return gemm(x, w, out, M=M, N=N, c1=K, lda=K, bias=bias, **kw)
+
+
+def groupnorm_stats(x, sums, n_slabs, rows, C_src, c_off, C_tot, groups=32):
+    lib = _lib.load()
+    _lib.check(lib.ew_groupnorm_stats_f16(_ptr(x), _ptr(sums), n_slabs, rows, C_src, c_off, C_tot, groups, _stream()),
+               "ew_groupnorm_stats_f16")
+
+
+def groupnorm_apply(x, sums, gamma, beta, y, n_slabs, rows, C_src, c_off, C_tot, eps, silu, groups=32):
+    lib = _lib.load()
+    _lib.check(lib.ew_groupnorm_apply_f16(_ptr(x), _ptr(sums), _ptr(gamma), _ptr(beta), _ptr(y), n_slabs, rows, C_src,
+                                          c_off, C_tot, groups, eps, 1 if silu else 0, _stream()),
+               "ew_groupnorm_apply_f16")
+
+
+def groupnorm(xs, gamma, beta, n_slabs, rows, eps, silu, groups=32, out=None):
+    """GroupNorm(+SiLU) over the channel concat of `xs` (list of [n_slabs*rows, C_i] fp16) -> [n_slabs*rows, sum C_i]."""
+    C_tot = sum(x.shape[-1] for x in xs)
+    dev = xs[0].device
+    sums = torch.zeros(n_slabs, groups, 2, dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty(n_slabs * rows, C_tot, dtype=torch.float16, device=dev)
+    off = 0
+    for x in xs:
+        groupnorm_stats(x, sums, n_slabs, rows, x.shape[-1], off, C_tot, groups)
+        off += x.shape[-1]
+    off = 0
+    for x in xs:
+        groupnorm_apply(x, sums, gamma, beta, out, n_slabs, rows, x.shape[-1], off, C_tot, eps, silu, groups)
+        off += x.shape[-1]
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, addvec=None, rows_per_group=1, x_out=None, out=None):
+    lib = _lib.load()
+    rows, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.ew_layernorm_f16(_ptr(x), _ptr(addvec), rows_per_group, _ptr(x_out), _ptr(gamma), _ptr(beta),
+                                    _ptr(out), rows, C, eps, _stream()), "ew_layernorm_f16")
+    return out
+
+
+def attn_spatial(q, k, vt, o, n_seq, S, heads, ld_qk, ld_vt, ld_o, scale=0.125):
+    lib = _lib.load()
+    _lib.check(lib.ew_attn_spatial_f16(_ptr(q), _ptr(k), _ptr(vt), _ptr(o), n_seq, S, heads, ld_qk, ld_vt, ld_o, scale,
+                                       _stream()), "ew_attn_spatial_f16")
+    return o
+
+
+def attn_temporal(q, k, v, o, B, T, S, heads, ld, ld_o, scale=0.125):
+    lib = _lib.load()
+    _lib.check(lib.ew_attn_temporal_f16(_ptr(q), _ptr(k), _ptr(v), _ptr(o), B, T, S, heads, ld, ld_o, scale, _stream()),
+               "ew_attn_temporal_f16")
+    return o
+
+
+def nchw_f32_to_nhwc_f16(x, y, ldc, c_off=0, scale=1.0):
+    lib = _lib.load()
+    _req(x, torch.float32, "x"); _req(y, torch.float16, "y")
+    N, C, H, W = x.shape
+    _lib.check(lib.ew_nchw_f32_to_nhwc_f16(_ptr(x), _ptr(y), N, C, H, W, ldc, c_off, scale, _stream()),
+               "ew_nchw_f32_to_nhwc_f16")
+    return y
+
+
+def nhwc_f16_to_nchw_f32(x, N, C, H, W, ldc):
+    lib = _lib.load()
+    _req(x, torch.float16, "x")
+    y = torch.empty(N, C, H, W, dtype=torch.float32, device=x.device)
+    _lib.check(lib.ew_nhwc_f16_to_nchw_f32(_ptr(x), _ptr(y), N, C, H, W, ldc, _stream()), "ew_nhwc_f16_to_nchw_f32")
+    return y
+
+
+def euler_cfg_step(eps, ld_eps, latents, guidance, sigma, sigma_next, next_in, cpad, T, h, w):
+    lib = _lib.load()
+    _req(latents, torch.float32, "latents"); _req(guidance, torch.float32, "guidance")
+    _lib.check(lib.ew_euler_cfg_step(_ptr(eps), ld_eps, _ptr(latents), _ptr(guidance), float(sigma), float(sigma_next),
+                                     _ptr(next_in), cpad, T, h, w, _stream()), "ew_euler_cfg_step")
+
+
+def plucker_embed(rays, c2w):
+    lib = _lib.load()
+    _req(rays, torch.float32, "rays"); _req(c2w, torch.float32, "c2w")
+    H, W, _ = rays.shape
+    N = c2w.shape[0]
+    out = torch.empty(N, 6, H, W, dtype=torch.float32, device=rays.device)
+    _lib.check(lib.ew_plucker_embed(_ptr(rays), _ptr(c2w), _ptr(out), N, H, W, _stream()), "ew_plucker_embed")
+    return out
+
+
+def cube2equi_gather(faces, lut, H, W):
+    """faces uint8 [V,6,res,res,3] (order right,left,bottom,top,front,back), lut int16 [H,W,3] -> uint8 [V,H,W,3]."""
+    lib = _lib.load()
+    _req(faces, torch.uint8, "faces"); _req(lut, torch.int16, "lut")
+    V, res = faces.shape[0], faces.shape[2]
+    pano = torch.empty(V, H, W, 3, dtype=torch.uint8, device=faces.device)
+    _lib.check(lib.ew_cube2equi_gather(_ptr(faces), _ptr(lut), _ptr(pano), V, H, W, res, _stream()), "ew_cube2equi_gather")
+    return pano
+
+
+def depth_unproject(depth, extr, intr):
+    lib = _lib.load()
+    _req(depth, torch.float32, "depth"); _req(extr, torch.float32, "extr"); _req(intr, torch.float32, "intr")
+    S, H, W = depth.shape
+    xyz = torch.empty(S, H, W, 3, dtype=torch.float32, device=depth.device)
+    _lib.check(lib.ew_depth_unproject(_ptr(depth), _ptr(extr), _ptr(intr), _ptr(xyz), S, H, W, _stream()),
+               "ew_depth_unproject")
+    return xyz
+
+
+def splat_cubemap(xyz, rgb, w2c, res, fx, fy, cx, cy, z_near):
+    """xyz [N,3] f32, rgb [N,3] u8, w2c [V,6,3,4] f32 -> faces u8 [V,6,res,res,3], zbuf u64-as-int64 [V,6,res,res]."""
+    lib = _lib.load()
+    _req(xyz, torch.float32, "xyz"); _req(rgb, torch.uint8, "rgb"); _req(w2c, torch.float32, "w2c")
+    V = w2c.shape[0]
+    zbuf = torch.full((V, 6, res, res), -1, dtype=torch.int64, device=xyz.device)  # 0xFFFF... as u64
+    _lib.check(lib.ew_splat_cubemap(_ptr(xyz), xyz.shape[0], _ptr(w2c), _ptr(zbuf), V, res, fx, fy, cx, cy, z_near,
+                                    _stream()), "ew_splat_cubemap")
+    faces = torch.empty(V, 6, res, res, 3, dtype=torch.uint8, device=xyz.device)
+    _lib.check(lib.ew_splat_resolve(_ptr(zbuf), _ptr(rgb), _ptr(faces), V, res, _stream()), "ew_splat_resolve")
+    return faces, zbuf
+
+
+def equi2pers(equi, rot, Hp, Wp, fov_x):
+    lib = _lib.load()
+    _req(equi, torch.uint8, "equi"); _req(rot, torch.float32, "rot")
+    F_, He, We, _ = equi.shape
+    out = torch.empty(F_, Hp, Wp, 3, dtype=torch.uint8, device=equi.device)
+    _lib.check(lib.ew_equi2pers(_ptr(equi), _ptr(rot), _ptr(out), F_, He, We, Hp, Wp, float(fov_x), _stream()), "ew_equi2pers")
+    return out

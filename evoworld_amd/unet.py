@@ -1,0 +1,544 @@
+"""UNetSpatioTemporalConditionModel on hand-written HIP kernels (gfx950).
+
+Call surface of the reference's U-Net shell, evoworld/trainer/unet_plucker.py:30-488 (itself a copy of
+diffusers' UNetSpatioTemporalConditionModel with conv_in widened to 18 channels,
+evoworld/trainer/trainer_utils.py:17-64):
+    unet = UNetSpatioTemporalConditionModel.from_pretrained(path, subfolder="unet")      # or (**config)
+    unet.config.in_channels / .addition_time_embed_dim / .num_frames / .sample_size
+    unet.add_embedding.linear_1.in_features
+    unet(sample[B,T,18,h,w], timestep, encoder_hidden_states=[B,1,1024], added_time_ids=[B,3],
+         return_dict=False) -> (Tensor[B,T,4,h,w],)
+State-dict keys are the diffusers keys, so a real SVD-Xtend/EvoWorld checkpoint loads.
+
+MI355X-first execution plan:
+  * activations live in HBM as fp16 channels-last [B*T*h*w, C]; conv <-> transformer hand-offs need no permute;
+  * every contraction is ew_gemm_f16 (MFMA, LDS-DMA staged); im2col / skip-concat / nearest-upsample / frame-axis
+    taps are DMA addressing modes; bias, time-embedding add, GEGLU, residual adds and AlphaBlender are epilogues;
+  * the single-KV-token cross attention is the exact identity out = to_out(to_v(ctx)); the two
+    weight matrices are folded at load time and the result enters the self-attention out-proj epilogue as a
+    per-batch-row bias -- the reference's q-proj / QK^T / out-proj work on it is dead and not executed;
+  * all time-embedding projections (44) and all cross-attention vectors (32) are two batched tiny GEMMs per forward.
+No torch.nn compute: torch provides device memory, the HIP stream and trivially small host-side glue only.
+"""
+import json
+import math
+import os
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+from .ops import A_CONV3X3, A_CONVT3, A_DENSE, ACT_GEGLU, ACT_NONE, ACT_SILU
+
+DEFAULT_CONFIG = dict(  # evoworld/trainer/unet_plucker.py:69-94 with in_channels=18 (trainer_utils.py:19)
+    sample_size=None, in_channels=18, out_channels=4,
+    down_block_types=("CrossAttnDownBlockSpatioTemporal",) * 3 + ("DownBlockSpatioTemporal",),
+    up_block_types=("UpBlockSpatioTemporal",) + ("CrossAttnUpBlockSpatioTemporal",) * 3,
+    block_out_channels=(320, 640, 1280, 1280), addition_time_embed_dim=256,
+    projection_class_embeddings_input_dim=768, layers_per_block=2, cross_attention_dim=1024,
+    transformer_layers_per_block=1, num_attention_heads=(5, 10, 20, 20), num_frames=25)
+
+CPAD_IN = 64  # conv_in input channels padded to one 64-wide K tile
+
+
+def _pad64(c):
+    return (c + 63) // 64 * 64
+
+
+# ------------------------------------------------------------------------------------------------
+# architecture walk: one place that knows the module tree (names = diffusers state-dict keys)
+# ------------------------------------------------------------------------------------------------
+def _arch(cfg):
+    boc = tuple(cfg["block_out_channels"])
+    heads = tuple(cfg["num_attention_heads"])
+    n = len(boc)
+    L = cfg["layers_per_block"]
+    res, trs, plan = [], [], []
+
+    def R(prefix, cin, cout, eps):
+        d = SimpleNamespace(p=prefix, cin=cin, cout=cout, eps=eps)
+        res.append(d)
+        return d
+
+    def TR(prefix, ch, nh):
+        d = SimpleNamespace(p=prefix, ch=ch, heads=nh)
+        trs.append(d)
+        return d
+
+    out = boc[0]
+    downs = []
+    for i in range(n):
+        cin, out = out, boc[i]
+        last = i == n - 1
+        blk = SimpleNamespace(res=[], attn=[], down=None)
+        for l in range(L):
+            blk.res.append(R(f"down_blocks.{i}.resnets.{l}", cin if l == 0 else out, out, 1e-5 if last else 1e-6))
+            if not last:
+                blk.attn.append(TR(f"down_blocks.{i}.attentions.{l}", out, heads[i]))
+        if not last:
+            blk.down = SimpleNamespace(p=f"down_blocks.{i}.downsamplers.0.conv", ch=out)
+        downs.append(blk)
+    mid = SimpleNamespace(res=[R("mid_block.resnets.0", boc[-1], boc[-1], 1e-5), R("mid_block.resnets.1", boc[-1], boc[-1], 1e-5)],
+                          attn=[TR("mid_block.attentions.0", boc[-1], heads[-1])])
+    rev, rheads = boc[::-1], heads[::-1]
+    ups = []
+    out = rev[0]
+    for i in range(n):
+        prev, out = out, rev[i]
+        cin = rev[min(i + 1, n - 1)]
+        blk = SimpleNamespace(res=[], attn=[], up=None)
+        for l in range(L + 1):
+            skip = cin if l == L else out
+            rin = prev if l == 0 else out
+            r = R(f"up_blocks.{i}.resnets.{l}", rin + skip, out, 1e-6)
+            r.split = (rin, skip)
+            blk.res.append(r)
+            if i > 0:
+                blk.attn.append(TR(f"up_blocks.{i}.attentions.{l}", out, rheads[i]))
+        if i < n - 1:
+            blk.up = SimpleNamespace(p=f"up_blocks.{i}.upsamplers.0.conv", ch=out)
+        ups.append(blk)
+    return SimpleNamespace(downs=downs, mid=mid, ups=ups, res=res, trs=trs)
+
+
+def param_spec(cfg):
+    """OrderedDict name -> (shape, kind) in module-registration order; kind in {w, b, gamma, beta, mix}."""
+    spec = OrderedDict()
+    boc = tuple(cfg["block_out_channels"])
+    temb = boc[0] * 4
+    X = cfg["cross_attention_dim"]
+
+    def lin(p, o, i, bias=True):
+        spec[p + ".weight"] = ((o, i), "w")
+        if bias:
+            spec[p + ".bias"] = ((o,), "b:%d" % i)
+
+    def conv(p, o, i, k):
+        spec[p + ".weight"] = ((o, i) + k, "w")
+        spec[p + ".bias"] = ((o,), "b:%d" % (i * math.prod(k)))
+
+    def norm(p, c):
+        spec[p + ".weight"] = ((c,), "gamma")
+        spec[p + ".bias"] = ((c,), "beta")
+
+    def resblock(r):
+        s, t = r.p + ".spatial_res_block", r.p + ".temporal_res_block"
+        norm(s + ".norm1", r.cin); conv(s + ".conv1", r.cout, r.cin, (3, 3)); lin(s + ".time_emb_proj", r.cout, temb)
+        norm(s + ".norm2", r.cout); conv(s + ".conv2", r.cout, r.cout, (3, 3))
+        if r.cin != r.cout:
+            conv(s + ".conv_shortcut", r.cout, r.cin, (1, 1))
+        norm(t + ".norm1", r.cout); conv(t + ".conv1", r.cout, r.cout, (3, 1, 1)); lin(t + ".time_emb_proj", r.cout, temb)
+        norm(t + ".norm2", r.cout); conv(t + ".conv2", r.cout, r.cout, (3, 1, 1))
+        spec[r.p + ".time_mixer.mix_factor"] = ((1,), "mix")
+
+    def attn(p, c, ctx):
+        lin(p + ".to_q", c, c, False); lin(p + ".to_k", c, ctx or c, False); lin(p + ".to_v", c, ctx or c, False)
+        lin(p + ".to_out.0", c, c)
+
+    def ff(p, c):
+        lin(p + ".net.0.proj", 8 * c, c); lin(p + ".net.2", c, 4 * c)
+
+    def transformer(t):
+        c = t.ch
+        norm(t.p + ".norm", c); lin(t.p + ".proj_in", c, c)
+        b = t.p + ".transformer_blocks.0"
+        norm(b + ".norm1", c); attn(b + ".attn1", c, None); norm(b + ".norm2", c); attn(b + ".attn2", c, X)
+        norm(b + ".norm3", c); ff(b + ".ff", c)
+        b = t.p + ".temporal_transformer_blocks.0"
+        norm(b + ".norm_in", c); ff(b + ".ff_in", c); norm(b + ".norm1", c); attn(b + ".attn1", c, None)
+        norm(b + ".norm2", c); attn(b + ".attn2", c, X); norm(b + ".norm3", c); ff(b + ".ff", c)
+        lin(t.p + ".time_pos_embed.linear_1", 4 * c, c); lin(t.p + ".time_pos_embed.linear_2", c, 4 * c)
+        spec[t.p + ".time_mixer.mix_factor"] = ((1,), "mix")
+        lin(t.p + ".proj_out", c, c)
+
+    conv("conv_in", boc[0], cfg["in_channels"], (3, 3))
+    lin("time_embedding.linear_1", temb, boc[0]); lin("time_embedding.linear_2", temb, temb)
+    lin("add_embedding.linear_1", temb, cfg["projection_class_embeddings_input_dim"]); lin("add_embedding.linear_2", temb, temb)
+    a = _arch(cfg)
+    for blk in a.downs:
+        for r in blk.res:
+            resblock(r)
+        for t in blk.attn:
+            transformer(t)
+        if blk.down:
+            conv(blk.down.p, blk.down.ch, blk.down.ch, (3, 3))
+    resblock(a.mid.res[0]); resblock(a.mid.res[1]); transformer(a.mid.attn[0])
+    for blk in a.ups:
+        for r in blk.res:
+            resblock(r)
+        for t in blk.attn:
+            transformer(t)
+        if blk.up:
+            conv(blk.up.p, blk.up.ch, blk.up.ch, (3, 3))
+    norm("conv_norm_out", boc[0]); conv("conv_out", cfg["out_channels"], boc[0], (3, 3))
+    return spec
+
+
+def random_state_dict(cfg, seed=0, device="cpu"):
+    """PyTorch-default-style initialisation (U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weights and biases, norm
+    gamma=1 beta=0, mix_factor=0.5) drawn from one generator in spec order."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = OrderedDict()
+    for name, (shape, kind) in param_spec(cfg).items():
+        if kind == "w":
+            fan_in = math.prod(shape[1:])
+            bound = 1.0 / math.sqrt(fan_in)
+            sd[name] = (torch.rand(shape, generator=g, device=device) * 2 - 1) * bound
+        elif kind.startswith("b:"):
+            bound = 1.0 / math.sqrt(int(kind[2:]))
+            sd[name] = (torch.rand(shape, generator=g, device=device) * 2 - 1) * bound
+        elif kind == "gamma":
+            sd[name] = torch.ones(shape, device=device)
+        elif kind == "beta":
+            sd[name] = torch.zeros(shape, device=device)
+        else:
+            sd[name] = torch.full(shape, 0.5, device=device)
+    return sd
+
+
+def _sinusoid(x, dim):
+    """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=x.device) / half)
+    args = x.reshape(-1, 1).float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+class UNetSpatioTemporalConditionModel:
+    def __init__(self, **config):
+        cfg = dict(DEFAULT_CONFIG)
+        cfg.update(config)
+        self._cfg = cfg
+        self.config = SimpleNamespace(**cfg)
+        self.arch = _arch(cfg)
+        self.device = None
+        self.w = None
+        self.add_embedding = SimpleNamespace(linear_1=SimpleNamespace(
+            in_features=cfg["projection_class_embeddings_input_dim"]))
+        self.dtype = torch.float16
+        self._pos_cache = {}
+        for hd, c in zip(cfg["num_attention_heads"], cfg["block_out_channels"]):
+            if c // hd != 64:
+                raise ValueError("evoworld_amd attention kernels are specialised to head_dim 64")
+
+    # ---------------- construction / loading ----------------
+    @classmethod
+    def from_pretrained(cls, path, subfolder=None, device="cuda", **_ignored):
+        """diffusers folder layout: <path>/<subfolder>/config.json + diffusion_pytorch_model.safetensors
+        (unified_loop_consistency.py:190-192)."""
+        root = os.path.join(path, subfolder) if subfolder else path
+        cfg = {}
+        cj = os.path.join(root, "config.json")
+        if os.path.exists(cj):
+            raw = json.load(open(cj))
+            cfg = {k: (tuple(v) if isinstance(v, list) else v) for k, v in raw.items() if k in DEFAULT_CONFIG}
+        m = cls(**cfg)
+        from safetensors.torch import load_file
+        for fn in ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors"):
+            f = os.path.join(root, fn)
+            if os.path.exists(f):
+                m.load_state_dict(load_file(f), device=device)
+                return m
+        raise FileNotFoundError(f"no diffusion_pytorch_model*.safetensors under {root}")
+
+    @classmethod
+    def from_random(cls, seed=0, device="cuda", **config):
+        m = cls(**config)
+        m.load_state_dict(random_state_dict(m._cfg, seed), device=device)
+        return m
+
+    def requires_grad_(self, _flag=False):
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, device=None, dtype=None):
+        if device is not None and self.w is not None and torch.device(device) != self.device:
+            raise NotImplementedError("weights are packed on the device given at load time")
+        return self
+
+    def load_state_dict(self, sd, device="cuda"):
+        spec = param_spec(self._cfg)
+        missing = [k for k in spec if k not in sd]
+        if missing:
+            raise KeyError(f"state dict is missing {len(missing)} keys, e.g. {missing[:3]}")
+        for k, (shape, _) in spec.items():
+            if tuple(sd[k].shape) != tuple(shape):
+                raise ValueError(f"{k}: expected shape {shape}, got {tuple(sd[k].shape)}")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("evoworld_amd.UNetSpatioTemporalConditionModel needs a GPU device (no CPU path)")
+        self._pack(sd)
+        return self
+
+    # ---------------- weight packing (once) ----------------
+    def _pack(self, sd):
+        dev = self.device
+        W = {}
+
+        def f32(k):
+            return sd[k].to(device=dev, dtype=torch.float32)
+
+        def h(t):
+            return t.to(torch.float16).contiguous()
+
+        def conv3(k, cpad=None):   # [O,I,3,3] -> [O, 9*I] tap-major
+            w = f32(k + ".weight").permute(0, 2, 3, 1)
+            if cpad:
+                w = torch.nn.functional.pad(w, (0, cpad - w.shape[-1]))
+            return h(w.reshape(w.shape[0], -1))
+
+        def convt(k):              # [O,I,3,1,1] -> [O, 3*I]
+            w = f32(k + ".weight")[:, :, :, 0, 0].permute(0, 2, 1)
+            return h(w.reshape(w.shape[0], -1))
+
+        def geglu(k):              # interleave value/gate rows in blocks of 16 (see ew_gemm_f16)
+            w, b = f32(k + ".weight"), f32(k + ".bias")
+            n = w.shape[0] // 2
+            idx = torch.arange(2 * n, device=dev).reshape(2, n // 16, 16).permute(1, 0, 2).reshape(-1)
+            return h(w[idx]), h(b[idx])
+
+        temb_w, temb_b, self._temb_off = [], [], {}
+        off = 0
+        for r in self.arch.res:
+            s, t = r.p + ".spatial_res_block", r.p + ".temporal_res_block"
+            d = {}
+            d["n1g"], d["n1b"] = h(f32(s + ".norm1.weight")), h(f32(s + ".norm1.bias"))
+            d["c1w"], d["c1b"] = conv3(s + ".conv1"), h(f32(s + ".conv1.bias"))
+            d["n2g"], d["n2b"] = h(f32(s + ".norm2.weight")), h(f32(s + ".norm2.bias"))
+            d["c2w"], d["c2b"] = conv3(s + ".conv2"), h(f32(s + ".conv2.bias"))
+            if r.cin != r.cout:
+                d["scw"] = h(f32(s + ".conv_shortcut.weight")[:, :, 0, 0])
+                d["scb"] = h(f32(s + ".conv_shortcut.bias"))
+            d["tn1g"], d["tn1b"] = h(f32(t + ".norm1.weight")), h(f32(t + ".norm1.bias"))
+            d["t1w"], d["t1b"] = convt(t + ".conv1"), h(f32(t + ".conv1.bias"))
+            d["tn2g"], d["tn2b"] = h(f32(t + ".norm2.weight")), h(f32(t + ".norm2.bias"))
+            d["t2w"], d["t2b"] = convt(t + ".conv2"), h(f32(t + ".conv2.bias"))
+            d["mix"] = float(torch.sigmoid(f32(r.p + ".time_mixer.mix_factor")).item())
+            for which in (s, t):
+                temb_w.append(f32(which + ".time_emb_proj.weight"))
+                temb_b.append(f32(which + ".time_emb_proj.bias"))
+                self._temb_off[which] = off
+                off += r.cout
+            W[r.p] = d
+        W["temb_w"], W["temb_b"] = h(torch.cat(temb_w)), h(torch.cat(temb_b))
+        self._temb_total = off
+
+        cv_w, cv_b, self._cv_off = [], [], {}
+        off = 0
+        for t in self.arch.trs:
+            d = {}
+            c = t.ch
+            d["ng"], d["nb"] = h(f32(t.p + ".norm.weight")), h(f32(t.p + ".norm.bias"))
+            d["piw"], d["pib"] = h(f32(t.p + ".proj_in.weight")), h(f32(t.p + ".proj_in.bias"))
+            d["pow"], d["pob"] = h(f32(t.p + ".proj_out.weight")), h(f32(t.p + ".proj_out.bias"))
+            d["mix"] = float(torch.sigmoid(f32(t.p + ".time_mixer.mix_factor")).item())
+            d["pe1w"], d["pe1b"] = h(f32(t.p + ".time_pos_embed.linear_1.weight")), h(f32(t.p + ".time_pos_embed.linear_1.bias"))
+            d["pe2w"], d["pe2b"] = h(f32(t.p + ".time_pos_embed.linear_2.weight")), h(f32(t.p + ".time_pos_embed.linear_2.bias"))
+            for tag, b in (("s", t.p + ".transformer_blocks.0"), ("t", t.p + ".temporal_transformer_blocks.0")):
+                for nm in (["norm_in"] if tag == "t" else []) + ["norm1", "norm3"]:
+                    d[f"{tag}_{nm}g"], d[f"{tag}_{nm}b"] = h(f32(f"{b}.{nm}.weight")), h(f32(f"{b}.{nm}.bias"))
+                q, k_, v = f32(b + ".attn1.to_q.weight"), f32(b + ".attn1.to_k.weight"), f32(b + ".attn1.to_v.weight")
+                if tag == "s":
+                    d["s_qk"], d["s_v"] = h(torch.cat([q, k_])), h(v)
+                else:
+                    d["t_qkv"] = h(torch.cat([q, k_, v]))
+                d[f"{tag}_ow"], d[f"{tag}_ob"] = h(f32(b + ".attn1.to_out.0.weight")), h(f32(b + ".attn1.to_out.0.bias"))
+                # cross attention with ONE key/value token: out = to_out(to_v(ctx)) -> fold the two matrices
+                cv_w.append(f32(b + ".attn2.to_out.0.weight") @ f32(b + ".attn2.to_v.weight"))
+                cv_b.append(f32(b + ".attn2.to_out.0.bias"))
+                self._cv_off[(t.p, tag)] = off
+                off += c
+                d[f"{tag}_f1w"], d[f"{tag}_f1b"] = geglu(b + ".ff.net.0.proj")
+                d[f"{tag}_f2w"], d[f"{tag}_f2b"] = h(f32(b + ".ff.net.2.weight")), h(f32(b + ".ff.net.2.bias"))
+                if tag == "t":
+                    d["t_fi1w"], d["t_fi1b"] = geglu(b + ".ff_in.net.0.proj")
+                    d["t_fi2w"], d["t_fi2b"] = h(f32(b + ".ff_in.net.2.weight")), h(f32(b + ".ff_in.net.2.bias"))
+            W[t.p] = d
+        W["cv_w"], W["cv_b"] = h(torch.cat(cv_w)), h(torch.cat(cv_b))
+        self._cv_total = off
+
+        for blk in self.arch.downs:
+            if blk.down:
+                W[blk.down.p] = (conv3(blk.down.p), h(f32(blk.down.p + ".bias")))
+        for blk in self.arch.ups:
+            if blk.up:
+                W[blk.up.p] = (conv3(blk.up.p), h(f32(blk.up.p + ".bias")))
+        W["conv_in"] = (conv3("conv_in", CPAD_IN), h(f32("conv_in.bias")))
+        W["conv_out"] = (conv3("conv_out"), h(f32("conv_out.bias")))
+        W["no_g"], W["no_b"] = h(f32("conv_norm_out.weight")), h(f32("conv_norm_out.bias"))
+        W["te1w"], W["te1b"] = h(f32("time_embedding.linear_1.weight")), h(f32("time_embedding.linear_1.bias"))
+        W["ae1w"], W["ae1b"] = h(f32("add_embedding.linear_1.weight")), h(f32("add_embedding.linear_1.bias"))
+        # emb = time_embedding.linear_2(.) + add_embedding.linear_2(.): one GEMM over the K-concat
+        W["e2w"] = h(torch.cat([f32("time_embedding.linear_2.weight"), f32("add_embedding.linear_2.weight")], dim=1))
+        W["e2b"] = h(f32("time_embedding.linear_2.bias") + f32("add_embedding.linear_2.bias"))
+        self.w = W
+
+    # ---------------- building blocks ----------------
+    def _conv3x3(self, x, x2, w, b, N, H, W_, Ho, Wo, stride=1, upsample=0, **kw):
+        c1 = x.shape[-1]
+        c2 = x2.shape[-1] if x2 is not None else 0
+        M = N * Ho * Wo
+        out = torch.empty(M, w.shape[0], dtype=torch.float16, device=x.device)
+        return ops.gemm(x, w, out, M=M, N=w.shape[0], c1=c1, lda=c1, a2=x2, c2=c2, lda2=c2, bias=b,
+                        mode=A_CONV3X3, conv=(N, H, W_, Ho, Wo, stride, upsample), **kw)
+
+    def _convt(self, x, w, b, B, T, P, **kw):
+        C = x.shape[-1]
+        M = B * T * P
+        out = torch.empty(M, w.shape[0], dtype=torch.float16, device=x.device)
+        return ops.gemm(x, w, out, M=M, N=w.shape[0], c1=C, lda=C, bias=b, mode=A_CONVT3, tconv=(B, T, P), **kw)
+
+    def _resblock(self, r, xs, tembs, B, T, H, W_):
+        """SpatioTemporalResBlock = ResnetBlock2D -> TemporalResnetBlock -> AlphaBlender."""
+        d = self.w[r.p]
+        N, HW = B * T, H * W_
+        rows = N * HW
+        s, t = r.p + ".spatial_res_block", r.p + ".temporal_res_block"
+        x1 = xs[0]
+        x2 = xs[1] if len(xs) > 1 else None
+        tb_s = tembs[:, self._temb_off[s]:]
+        tb_t = tembs[:, self._temb_off[t]:]
+        hN = ops.groupnorm(xs, d["n1g"], d["n1b"], N, HW, r.eps, True)
+        h1 = self._conv3x3(hN, None, d["c1w"], d["c1b"], N, H, W_, H, W_, rowbias=tb_s, rows_per_group=T * HW,
+                           ld_rowbias=self._temb_total)
+        h2 = ops.groupnorm([h1], d["n2g"], d["n2b"], N, HW, r.eps, True)
+        if "scw" in d:
+            sc = torch.empty(rows, r.cout, dtype=torch.float16, device=x1.device)
+            c1 = x1.shape[-1]
+            c2 = x2.shape[-1] if x2 is not None else 0
+            ops.gemm(x1, d["scw"], sc, M=rows, N=r.cout, c1=c1, lda=c1, a2=x2, c2=c2, lda2=c2, bias=d["scb"])
+        else:
+            sc = x1
+        xsp = self._conv3x3(h2, None, d["c2w"], d["c2b"], N, H, W_, H, W_, r1=sc, ld_r1=r.cout)
+        g1 = ops.groupnorm([xsp], d["tn1g"], d["tn1b"], B, T * HW, r.eps, True)
+        t1 = self._convt(g1, d["t1w"], d["t1b"], B, T, HW, rowbias=tb_t, rows_per_group=T * HW,
+                         ld_rowbias=self._temb_total)
+        g2 = ops.groupnorm([t1], d["tn2g"], d["tn2b"], B, T * HW, r.eps, True)
+        # x_temporal = xsp + conv2(..); out = (1-a)*xsp + a*x_temporal with a = sigmoid(mix)  (switch_spatial_to_temporal_mix)
+        return self._convt(g2, d["t2w"], d["t2b"], B, T, HW, r1=xsp, ld_r1=r.cout, c_acc=d["mix"], c_r1=1.0)
+
+    def _pos_emb(self, t, B, T):
+        key = (t.p, B, T)
+        if key not in self._pos_cache:
+            d = self.w[t.p]
+            sin = _sinusoid(torch.arange(T, device=self.device), t.ch).to(torch.float16).contiguous()
+            e = ops.linear(ops.linear(sin, d["pe1w"], d["pe1b"], act=ACT_SILU), d["pe2w"], d["pe2b"])
+            self._pos_cache[key] = e.repeat(B, 1).contiguous()
+        return self._pos_cache[key]
+
+    def _transformer(self, t, x, cvecs, B, T, H, W_):
+        """TransformerSpatioTemporalModel."""
+        d = self.w[t.p]
+        C, N, S = t.ch, B * T, H * W_
+        rows = N * S
+        dev = x.device
+        cv_s = cvecs[:, self._cv_off[(t.p, "s")]:]
+        cv_t = cvecs[:, self._cv_off[(t.p, "t")]:]
+        hn = ops.groupnorm([x], d["ng"], d["nb"], N, S, 1e-6, False)
+        h = ops.linear(hn, d["piw"], d["pib"])
+        # --- spatial BasicTransformerBlock ---
+        n1 = ops.layernorm(h, d["s_norm1g"], d["s_norm1b"])
+        qk = ops.linear(n1, d["s_qk"])
+        vt = torch.empty(C, rows, dtype=torch.float16, device=dev)
+        ops.gemm(d["s_v"], n1, vt, M=C, N=rows, c1=C, lda=C)          # V^T = W_v X^T (swapped operands)
+        ao = torch.empty(rows, C, dtype=torch.float16, device=dev)
+        ops.attn_spatial(qk, qk[:, C:], vt, ao, N, S, t.heads, 2 * C, rows, C)
+        del qk, vt
+        # attn1 out-proj + residual + folded single-token cross attention (per batch row)
+        h = ops.linear(ao, d["s_ow"], d["s_ob"], rowbias=cv_s, rows_per_group=T * S, ld_rowbias=self._cv_total,
+                       r1=h, ld_r1=C)
+        n3 = ops.layernorm(h, d["s_norm3g"], d["s_norm3b"])
+        ffh = ops.linear(n3, d["s_f1w"], d["s_f1b"], act=ACT_GEGLU)
+        h = ops.linear(ffh, d["s_f2w"], d["s_f2b"], r1=h, ld_r1=C)
+        del ffh
+        # --- TemporalBasicTransformerBlock on frame-major tokens (regroup = addressing) ---
+        hm = torch.empty_like(h)
+        nin = ops.layernorm(h, d["t_norm_ing"], d["t_norm_inb"], addvec=self._pos_emb(t, B, T), rows_per_group=S, x_out=hm)
+        ffh = ops.linear(nin, d["t_fi1w"], d["t_fi1b"], act=ACT_GEGLU)
+        hm = ops.linear(ffh, d["t_fi2w"], d["t_fi2b"], r1=hm, ld_r1=C)
+        del ffh
+        n1 = ops.layernorm(hm, d["t_norm1g"], d["t_norm1b"])
+        qkv = ops.linear(n1, d["t_qkv"])
+        ops.attn_temporal(qkv, qkv[:, C:], qkv[:, 2 * C:], ao, B, T, S, t.heads, 3 * C, C)
+        del qkv
+        hm = ops.linear(ao, d["t_ow"], d["t_ob"], rowbias=cv_t, rows_per_group=T * S, ld_rowbias=self._cv_total,
+                        r1=hm, ld_r1=C)
+        n3 = ops.layernorm(hm, d["t_norm3g"], d["t_norm3b"])
+        ffh = ops.linear(n3, d["t_f1w"], d["t_f1b"], act=ACT_GEGLU)
+        a = d["mix"]  # AlphaBlender: a*x_spatial + (1-a)*x_temporal, x_temporal = hm + ff(..)
+        hb = ops.linear(ffh, d["t_f2w"], d["t_f2b"], c_acc=1.0 - a, r1=hm, ld_r1=C, c_r1=1.0 - a, r2=h, ld_r2=C, c_r2=a)
+        del ffh
+        return ops.linear(hb, d["pow"], d["pob"], r1=x, ld_r1=C)
+
+    # ---------------- forward ----------------
+    def forward_nhwc(self, x, timestep, encoder_hidden_states, added_time_ids, B, T, H, W_):
+        """x: fp16 [B*T*H*W, 64] channels-last (18 real channels, zero padded) -> fp16 [B*T*H*W, 4]."""
+        cfg, Wt = self._cfg, self.w
+        dev = x.device
+        boc = cfg["block_out_channels"]
+        N = B * T
+        ts = torch.as_tensor(timestep, dtype=torch.float32, device=dev).reshape(-1).expand(B)
+        t_emb = _sinusoid(ts, boc[0]).to(torch.float16).contiguous()
+        a_emb = _sinusoid(added_time_ids.to(dev).flatten(), cfg["addition_time_embed_dim"]).reshape(B, -1)
+        a_emb = a_emb.to(torch.float16).contiguous()
+        h1 = ops.linear(t_emb, Wt["te1w"], Wt["te1b"], act=ACT_SILU)
+        h2 = ops.linear(a_emb, Wt["ae1w"], Wt["ae1b"], act=ACT_SILU)
+        td = boc[0] * 4
+        semb = torch.empty(B, td, dtype=torch.float16, device=dev)   # silu(emb): the only form emb is consumed in
+        ops.gemm(h1, Wt["e2w"], semb, M=B, N=td, c1=td, lda=td, a2=h2, c2=td, lda2=td, bias=Wt["e2b"], act=ACT_SILU)
+        tembs = ops.linear(semb, Wt["temb_w"], Wt["temb_b"])          # all 44 time_emb_proj at once
+        ehs = encoder_hidden_states.to(device=dev, dtype=torch.float16).reshape(B, -1).contiguous()
+        cvecs = ops.linear(ehs, Wt["cv_w"], Wt["cv_b"])               # all 32 cross-attention vectors at once
+
+        h = self._conv3x3(x, None, *Wt["conv_in"], N, H, W_, H, W_)
+        skips = [(h, H, W_)]
+        for blk in self.arch.downs:
+            for l, r in enumerate(blk.res):
+                h = self._resblock(r, [h], tembs, B, T, H, W_)
+                if blk.attn:
+                    h = self._transformer(blk.attn[l], h, cvecs, B, T, H, W_)
+                skips.append((h, H, W_))
+            if blk.down:
+                w, b = Wt[blk.down.p]
+                h = self._conv3x3(h, None, w, b, N, H, W_, H // 2, W_ // 2, stride=2)
+                H, W_ = H // 2, W_ // 2
+                skips.append((h, H, W_))
+        m = self.arch.mid
+        h = self._resblock(m.res[0], [h], tembs, B, T, H, W_)
+        h = self._transformer(m.attn[0], h, cvecs, B, T, H, W_)
+        h = self._resblock(m.res[1], [h], tembs, B, T, H, W_)
+        for blk in self.arch.ups:
+            for l, r in enumerate(blk.res):
+                sk, sh, sw = skips.pop()
+                assert (sh, sw) == (H, W_)
+                h = self._resblock(r, [h, sk], tembs, B, T, H, W_)   # cat([hidden, skip], dim=1) by addressing
+                if blk.attn:
+                    h = self._transformer(blk.attn[l], h, cvecs, B, T, H, W_)
+            if blk.up:
+                w, b = Wt[blk.up.p]
+                h = self._conv3x3(h, None, w, b, N, H, W_, 2 * H, 2 * W_, upsample=1)
+                H, W_ = 2 * H, 2 * W_
+        hn = ops.groupnorm([h], Wt["no_g"], Wt["no_b"], N, H * W_, 1e-5, True)
+        return self._conv3x3(hn, None, *Wt["conv_out"], N, H, W_, H, W_)
+
+    @torch.no_grad()
+    def __call__(self, sample, timestep, encoder_hidden_states, added_time_ids, return_dict=True):
+        if self.w is None:
+            raise RuntimeError("weights not loaded")
+        if sample.ndim != 5 or sample.shape[2] != self._cfg["in_channels"]:
+            raise ValueError(f"sample must be [B,T,{self._cfg['in_channels']},h,w], got {tuple(sample.shape)}")
+        B, T, C, H, W_ = sample.shape
+        if H % 8 or W_ % 8:
+            raise ValueError("latent height/width must be multiples of 8 (three stride-2 levels)")
+        x = torch.zeros(B * T * H * W_, CPAD_IN, dtype=torch.float16, device=self.device)
+        ops.nchw_f32_to_nhwc_f16(sample.to(device=self.device, dtype=torch.float32).reshape(B * T, C, H, W_).contiguous(),
+                                 x, CPAD_IN)
+        eps = self.forward_nhwc(x, timestep, encoder_hidden_states, added_time_ids, B, T, H, W_)
+        oc = self._cfg["out_channels"]
+        out = ops.nhwc_f16_to_nchw_f32(eps, B * T, oc, H, W_, oc).reshape(B, T, oc, H, W_)
+        if not return_dict:
+            return (out,)
+        return SimpleNamespace(sample=out)

@@ -1,0 +1,171 @@
+/* evoworld_hip.h -- C ABI of libevoworld_hip.so (gfx950 / MI355X).
+ *
+ * The reference (JiahaoPlus/EvoWorld) has no FFI / plugin registry: its hot path is Python calling
+ * third-party libraries (diffusers / torch / open3d / pyequilib).  This header is the drop-in boundary
+ * the Python call surface (evoworld_amd/ *.py, mirroring evoworld/pipeline, evoworld/trainer/unet_plucker,
+ * utils/plucker_embedding, evoworld/reprojection) binds through ctypes.  Each entry point cites the
+ * reference interface (file:line under /root/reference) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (a torch tensor's data_ptr()); the library
+ *     never allocates, frees or synchronises; every call is asynchronous on `stream` (a hipStream_t
+ *     passed as void*; NULL = the default stream).
+ *   - activations are fp16 channels-last: [N, H, W, C] == [tokens, C] row-major.
+ *   - return value: 0 = OK, <0 = error; ew_last_error() returns a thread-local message.
+ */
+#ifndef EVOWORLD_HIP_H
+#define EVOWORLD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int ew_status;
+#define EW_OK 0
+#define EW_ERR_INVALID_ARG (-1)
+#define EW_ERR_UNSUPPORTED (-2)
+#define EW_ERR_HIP (-3)
+
+#define EW_ABI_VERSION 1
+int ew_abi_version(void);
+const char* ew_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused MFMA GEMM / implicit-GEMM convolution  (fp16 in, fp32 accumulate, fp16 out).
+ *   acc[m][n] = sum_k A(m,k) * W[n][k]                    W row-major [N, K], K = taps*(c1+c2)
+ *   v   = acc + bias[n] + rowbias[(m / rows_per_group) * ld_rowbias + n]
+ *   v   = act(v)            act 0: none; 1: SiLU; 2: GEGLU -> out has N/2 columns (see w layout note below)
+ *   out = c_acc*v + c_r1*r1[m][n] + c_r2*r2[m][n]
+ * A-operand addressing modes (the gather happens in the global->LDS DMA address, no im2col buffer):
+ *   EW_A_DENSE   A(m, k)          = a[m*lda + k]                      (k < c1; then a2[m*lda2 + k-c1])
+ *   EW_A_CONV3X3 m -> (img, oy, ox) on an [n_img, h_out, w_out] grid; tap = ky*3+kx;
+ *                A(m, tap*C + c)  = in[img, iy, ix, c], iy = oy*stride+ky-1, ix = ox*stride+kx-1, zero
+ *                outside; with upsample=1 the input is read as nearest-x2 upsampled ([h_in,w_in] -> 2x).
+ *   EW_A_CONVT3  m -> (b, t, p) on a [B, T, P] grid; A(m, kt*C + c) = in[b, t+kt-1, p, c], zero outside.
+ * In the conv modes channels [0,c1) come from `a`, [c1,c1+c2) from `a2` (the up-block skip concat,
+ * evoworld/trainer/unet_plucker.py:458-475 + diffusers up blocks) without materialising the concat.
+ * Replaces: torch.nn.Linear / Conv2d / Conv3d(3,1,1) calls inside the diffusers blocks instantiated at
+ * evoworld/trainer/unet_plucker.py:126-244 (ResnetBlock2D, TemporalResnetBlock, Down/Upsample2D, Attention
+ * projections, FeedForward/GEGLU, proj_in/out) and the AlphaBlender / residual adds around them.
+ * Constraints: c1 % 64 == 0, c2 % 64 == 0 (pad channels), all pointers 16-byte aligned, ld* % 8 == 0.
+ * GEGLU weight layout: rows are pre-interleaved in blocks of 16: tile rows [32q,32q+16) = value rows
+ * 16q.., [32q+16,32q+32) = gate rows (N/2 + 16q..); bias likewise (evoworld_amd.unet packs this).
+ */
+enum { EW_A_DENSE = 0, EW_A_CONV3X3 = 1, EW_A_CONVT3 = 2 };
+enum { EW_ACT_NONE = 0, EW_ACT_SILU = 1, EW_ACT_GEGLU = 2 };
+
+typedef struct ew_gemm_args {
+    const void* a;      /* fp16 */
+    const void* a2;     /* fp16 or NULL */
+    const void* w;      /* fp16 [N, K] */
+    const void* bias;   /* fp16 [N] or NULL */
+    const void* rowbias;/* fp16 [G, N] or NULL */
+    const void* r1;     /* fp16 [M, ld_r1] or NULL */
+    const void* r2;     /* fp16 [M, ld_r2] or NULL */
+    void* out;          /* fp16 [M, ld_out] */
+    const void* zero_page; /* >= 256 bytes of device zeros (conv padding source) */
+    int M, N;
+    int c1, c2;         /* channels from a / a2 per tap */
+    int lda, lda2;      /* row strides (elements) of a / a2 */
+    int ld_out, ld_r1, ld_r2, ld_rowbias;
+    int mode;           /* EW_A_* */
+    int n_img, h_in, w_in, h_out, w_out, stride, upsample; /* EW_A_CONV3X3 */
+    int tB, tT, tP;     /* EW_A_CONVT3 */
+    int rows_per_group; /* rowbias group size in rows (>=1) */
+    int act;            /* EW_ACT_* */
+    float c_acc, c_r1, c_r2;
+} ew_gemm_args;
+
+ew_status ew_gemm_f16(const ew_gemm_args* args, void* stream);
+
+/* GroupNorm statistics + apply, channels-last fp16, over a (virtual) channel concat.
+ * The normalised tensor has C_tot channels in `groups` groups; this call handles the C_src channels
+ * [c_off, c_off+C_src) that live in tensor `x` ([n_slabs*rows, C_src]); a skip-concat input is covered by
+ * two calls (one per source) -- groups may straddle the seam.
+ * stats: sums[n][g] += (sum, sumsq) (fp32, atomics; `sums` [n_slabs, groups, 2] must be zeroed first);
+ *        slab n = `rows` consecutive rows (rows = H*W for the per-frame GN of ResnetBlock2D / transformer
+ *        norm / conv_norm_out; rows = T*H*W for TemporalResnetBlock's GN over [B,C,T,H,W]).
+ * apply: y[row][c_off+c] = (x-mean)*rstd*gamma[c_off+c]+beta[c_off+c], optional SiLU; y row stride = C_tot.
+ * Replaces torch.nn.GroupNorm + SiLU at the diffusers blocks instantiated by
+ * evoworld/trainer/unet_plucker.py:161-233 and conv_norm_out (:236, 478-479). */
+ew_status ew_groupnorm_stats_f16(const void* x, float* sums, int n_slabs, int rows, int C_src, int c_off, int C_tot,
+                                 int groups, void* stream);
+ew_status ew_groupnorm_apply_f16(const void* x, const float* sums, const void* gamma, const void* beta, void* y,
+                                 int n_slabs, int rows, int C_src, int c_off, int C_tot, int groups, float eps,
+                                 int silu, void* stream);
+
+/* LayerNorm over the last dim (fp16 in/out, fp32 statistics).  Optional fused pre-add:
+ * x' = x + addvec[row / rows_per_group][:] is what gets normalised, and x' is written to x_out (fp16) when
+ * non-NULL (the time_pos_embed add in TransformerSpatioTemporalModel).  C % 8 == 0, C <= 2048.
+ * Replaces torch.nn.LayerNorm in Basic/TemporalBasicTransformerBlock (diffusers, via unet_plucker.py:13). */
+ew_status ew_layernorm_f16(const void* x, const void* addvec, int rows_per_group, void* x_out, const void* gamma,
+                           const void* beta, void* y, int rows, int C, float eps, void* stream);
+
+/* Spatial self-attention core, head_dim 64: o = softmax(q k^T * scale) v per (sequence, head), flash-tiled
+ * on MFMA 32x32x16 with the swapped product S^T = K Q^T so each query's softmax row is lane-local.
+ * q,k: fp16 token-major with row stride ld_qk (head h at +64h); vt: V TRANSPOSED [heads*64, n_seq*S]
+ * (row = channel, tokens contiguous; produced by ew_gemm_f16 with swapped operands); o: [n_seq*S, ld_o].
+ * Replaces F.scaled_dot_product_attention in AttnProcessor2_0 for BasicTransformerBlock.attn1
+ * (SURVEY.md §8a U10). */
+ew_status ew_attn_spatial_f16(const void* q, const void* k, const void* vt, void* o, int n_seq, int S, int heads,
+                              int ld_qk, long long ld_vt, int ld_o, float scale, void* stream);
+
+/* Temporal self-attention core over the frame axis (T <= 32, head_dim 64) on frame-major tokens
+ * [B, T, S, *]: sequence (b, s) attends over t -- the [B*T,S,C] <-> [B*S,T,C] regroup of
+ * TemporalBasicTransformerBlock is done by addressing, not by a copy.  q,k,v row stride ld; o row stride ld_o.
+ * Replaces SDPA in TemporalBasicTransformerBlock.attn1. */
+ew_status ew_attn_temporal_f16(const void* q, const void* k, const void* v, void* o, int B, int T, int S, int heads,
+                               int ld, int ld_o, float scale, void* stream);
+
+/* Layout changes at the U-Net boundary.
+ * nchw->nhwc: y[n,h,w,c_off+c] = fp16(scale * x[n,c,h,w]) for c < C (row stride ldc; other channels untouched).
+ * nhwc->nchw: y[n,c,h,w] = fp32(x[n,h,w,c]) for c < C. */
+ew_status ew_nchw_f32_to_nhwc_f16(const float* x, void* y, int N, int C, int H, int W, int ldc, int c_off, float scale,
+                                  void* stream);
+ew_status ew_nhwc_f16_to_nchw_f32(const void* x, float* y, int N, int C, int H, int W, int ldc, void* stream);
+
+/* Fused denoise-step glue: CFG combine + Euler (v-prediction) step + scale_model_input + concat for the next
+ * step.  eps: fp16 NHWC [2*T, h, w, ld_eps] (rows [0,T) uncond, [T,2T) cond; first 4 channels);
+ * latents: fp32 [T,4,h,w] state (updated in place); guidance [T]; next_in: fp16 NHWC [2*T,h,w,cpad], channels
+ * [0,4) are rewritten with latents_new / sqrt(sigma_next^2+1) for both CFG rows (cond channels untouched).
+ * Replaces evoworld/pipeline/pipeline_evoworld.py:691-695,709-714 + EulerDiscreteScheduler.step/scale_model_input. */
+ew_status ew_euler_cfg_step(const void* eps, int ld_eps, float* latents, const float* guidance, float sigma,
+                            float sigma_next, void* next_in, int cpad, int T, int h, int w, void* stream);
+
+/* Plücker embedding: out[n, 0:3, y, x] = R_n d(y,x); out[n, 3:6] = t_n x (R_n d)  (fp32).
+ * rays [H,W,3] fp32, c2w [N,3,4] fp32 -> out [N,6,H,W] fp32.
+ * Replaces utils/plucker_embedding.py:221-255 (ray_c2w_to_plucker). */
+ew_status ew_plucker_embed(const float* rays, const float* c2w, float* out, int N, int H, int W, void* stream);
+
+/* Cube -> equirect gather through the integer LUT (face, v, u) int16 [H,W,3]; faces uint8
+ * [V,6,res,res,3] (face order right,left,bottom,top,front,back) -> pano uint8 [V,H,W,3].
+ * Replaces CubemapRenderer.cube_to_equirectangular_cuda, reproject_vggt_open3d_utils.py:542-614. */
+ew_status ew_cube2equi_gather(const uint8_t* faces, const int16_t* lut, uint8_t* pano, int V, int H, int W, int res,
+                              void* stream);
+
+/* Depth lift: xyz[s,y,x] = R_s^T (K_s^-1 [u,v,1] z - t_s); depth [S,H,W] f32, extr [S,3,4] world->cam,
+ * intr [S,3,3] -> xyz [S,H,W,3] f32.  Replaces vggt unproject_depth_map_to_point_map
+ * (unified_loop_consistency.py:352,365-367). */
+ew_status ew_depth_unproject(const float* depth, const float* extr, const float* intr, float* xyz, int S, int H, int W,
+                             void* stream);
+
+/* Point splat into cubemap z-buffers: for view v, face f: p_cam = w2c[v][f] * p; u = fx*x/z+cx, ...;
+ * nearest pixel, min depth wins (64-bit atomicMin of depth-bits<<32 | point index), z > near.
+ * zbuf: uint64 [V,6,res,res] pre-filled with 0xFF..FF; resolve writes rgb (0 background).
+ * Replaces Open3D OffscreenRenderer point rendering driven by render_face/render_cubemap,
+ * reproject_vggt_open3d_utils.py:617-666 (parity unpinned: Filament GL). */
+ew_status ew_splat_cubemap(const float* xyz, size_t npts, const float* w2c, unsigned long long* zbuf, int V, int res,
+                           float fx, float fy, float cx, float cy, float z_near, void* stream);
+ew_status ew_splat_resolve(const unsigned long long* zbuf, const uint8_t* rgb, uint8_t* faces, int V, int res,
+                           void* stream);
+
+/* Equirect -> perspective bilinear gather (pyequilib Equi2Pers restatement; unified_loop_consistency.py:299-334).
+ * equi uint8 [F,He,We,3]; rot [F,3,3] f32 (camera->pano rotation); out uint8 [F,Hp,Wp,3]. */
+ew_status ew_equi2pers(const uint8_t* equi, const float* rot, uint8_t* out, int F, int He, int We, int Hp, int Wp,
+                       float fov_x_deg, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
