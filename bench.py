@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- EvoWorld per-clip denoise throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+A "step" = ONE CLIP through the hot path at BASELINE.json configs[1]: 576x1024 panorama, 25 frames, 25
+EulerDiscrete steps, CFG on (U-Net batch 2), random-init SVD-Xtend U-Net (in_channels 18), synthetic inputs
+already resident in HBM.  N>1: one process per GPU (torch.distributed.run), one independent clip per rank
+(weak scaling, no collective inside the loop; the final latents are all-gathered).  Rank 0 prints ONE JSON line.
+`value` = frames/s over the whole job = N * 25 * K / max-over-ranks(seconds).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_TFLOP_PER_FORWARD = 154.31      # SURVEY.md §8d, config 2, dead cross-attention work removed
+PEAK_F16_DENSE_TFLOPS = 2500.0       # MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16 MFMA
+
+
+def synth_inputs(T, h, w, seed, device):
+    """SURVEY.md §8d config 2 synthetic clip (seeded on CPU so that RNG differences between stacks vanish)."""
+    from evoworld_amd.geometry import xyz_euler_to_three_by_four_matrix_batch
+    from evoworld_amd.plucker import equirectangular_to_ray, ray_c2w_to_plucker
+    g = lambda s: torch.Generator().manual_seed(seed * 100 + s)
+    latents = torch.randn(1, T, 4, h, w, generator=g(1))
+    image_latents = torch.randn(1, T + 1, 4, h, w, generator=g(2))
+    ehs = torch.randn(1, 1, 1024, generator=g(3))
+    i = torch.arange(T, dtype=torch.float32)
+    psi = 95.0 + 3.6 * i
+    pose = torch.stack([0.04 * i * torch.sin(psi * math.pi / 180), torch.zeros(T), 0.04 * i * torch.cos(psi * math.pi / 180),
+                        torch.zeros(T), psi, torch.zeros(T)], dim=1)
+    c2w = xyz_euler_to_three_by_four_matrix_batch(pose, relative=True)
+    plucker = ray_c2w_to_plucker(torch.tensor(equirectangular_to_ray(h, w)).float().to(device), c2w.to(device))[None]
+    return latents.to(device), image_latents.to(device), ehs.to(device), plucker
+
+
+def cpu_baseline(T_sample=1):
+    """The reference's CPU path (diffusers fp32 on PyTorch) restated by the oracle, timed on the host cores on a
+    BOUNDED sample: one full-resolution U-Net forward over B=2 x T_sample frames (incl. the reference's dead
+    cross-attention work).  Per-frame cost is linear in frames, so a 25-frame forward = 25/T_sample samples."""
+    from oracle.unet_ref import UNetSpatioTemporalConditionModelRef
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with torch.device("meta"):
+        m = UNetSpatioTemporalConditionModelRef()
+    m = m.to_empty(device="cpu").eval()
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.uniform_(-0.02, 0.02, generator=g)
+    x = torch.randn(2, T_sample, 18, 72, 128, generator=g)
+    ehs = torch.randn(2, 1, 1024, generator=g)
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
+    t0 = time.time()
+    m(x, torch.tensor(1.0), ehs, ids, exec_dead_cross_attn=True)
+    dt = time.time() - t0
+    t_forward = dt * (25.0 / T_sample)
+    fps = 25.0 / (25 * t_forward)
+    return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 fp32 oracle U-Net forward at 72x128 latents over B=2 x T={T_sample} frames ({dt:.1f} s), "
+                      f"scaled x{25 // T_sample} to T=25 and x25 denoise steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="clips timed per rank")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=25)
+    ap.add_argument("--height", type=int, default=576)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--denoise-steps", type=int, default=25)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tiny", action="store_true", help="shrunken U-Net (plumbing check only; result flagged invalid)")
+    args = ap.parse_args()
+
+    from evoworld_amd import distributed as D
+    rank, world, local = D.init()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from evoworld_amd import ops
+    from evoworld_amd.pipeline import StableVideoDiffusionPipeline
+    from evoworld_amd.scheduler import EulerDiscreteScheduler
+    from evoworld_amd.unet import UNetSpatioTemporalConditionModel
+    cfg = {}
+    if args.tiny:
+        cfg = dict(block_out_channels=(64, 128, 256, 256), addition_time_embed_dim=64,
+                   projection_class_embeddings_input_dim=192, cross_attention_dim=1024, num_attention_heads=(1, 2, 4, 4))
+    unet = UNetSpatioTemporalConditionModel.from_random(seed=0, device=dev, **cfg)
+    pipe = StableVideoDiffusionPipeline(unet=unet, scheduler=EulerDiscreteScheduler())
+    T, h, w = args.frames, args.height // 8, args.width // 8
+    latents, image_latents, ehs, plucker = synth_inputs(T, h, w, seed=10 + rank, device=dev)
+    dummy_image = torch.zeros(1, 3, args.height, args.width, device=dev)
+
+    def one_clip():
+        out = pipe(dummy_image, height=args.height, width=args.width, num_frames=T, num_inference_steps=args.denoise_steps,
+                   latents=latents, output_type="latent", plucker_embedding=plucker, image_latents=image_latents,
+                   image_embeddings=ehs, mask_mem=False).frames
+        return D.gather_results(out)
+
+    for _ in range(args.warmup):
+        one_clip()
+    # live HIP-event timing of the U-Net forward (the kernel chain the roofline is quoted on), on the launch stream
+    fw_events = []
+    orig_forward = unet.forward_nhwc
+
+    def timed_forward(*a, **k):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = orig_forward(*a, **k)
+        e.record()
+        fw_events.append((s, e))
+        return r
+    unet.forward_nhwc = timed_forward
+
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = one_clip()
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = time.perf_counter() - t0
+    dt = D.max_over_ranks(dt, dev)
+    unet.forward_nhwc = orig_forward
+    finite = all(bool(torch.isfinite(r).all()) for r in res)
+
+    if rank == 0:
+        fw_ms = sum(s.elapsed_time(e) for s, e in fw_events) / max(1, len(fw_events))
+        full = (not args.tiny) and (T, args.height, args.width, args.denoise_steps) == (25, 576, 1024, 25)
+        ach = ALGO_TFLOP_PER_FORWARD / (fw_ms / 1e3) if full else None
+        line = {
+            "metric": "panoramic frames/sec per clip (576x1024x25f, 25 denoise steps)",
+            "value": world * T * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"configs[1]: single clip {args.height}x{args.width}x{T}f, {args.denoise_steps} EulerDiscrete "
+                                   "steps, CFG batch 2, random-init SVD-Xtend U-Net (in_channels 18), one clip per GPU",
+                       "unet_forward_ms": fw_ms, "valid": bool(full and finite)},
+            "roofline": {"bound": "mfma", "kernel": "U-Net denoise step (all launches of one forward, HIP events on the launch stream)",
+                         "achieved": ach, "peak": PEAK_F16_DENSE_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (ach / PEAK_F16_DENSE_TFLOPS) if ach else None, "traffic": None,
+                         "algorithmic_tflop_per_launch": ALGO_TFLOP_PER_FORWARD},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    D.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,241 @@
+"""StableVideoDiffusionPipeline with EvoWorld conditioning -- the reference's call surface
+(evoworld/pipeline/pipeline_evoworld.py:197-741) over the HIP U-Net and the fused denoise-step kernel.
+
+    pipe = StableVideoDiffusionPipeline(unet=unet, scheduler=EulerDiscreteScheduler(), vae=vae, image_encoder=clip)
+    frames = pipe(image, height=576, width=1024, num_frames=25, decode_chunk_size=8, motion_bucket_id=127, fps=7,
+                  noise_aug_strength=0.02, plucker_embedding=..., memorized_pixel_values=..., mask_mem=False).frames[0]
+
+Same 23 keyword parameters, same conditioning assembly (first-frame latent repeated, memory latents, Plücker
+duplicated -- NOT zeroed -- on the unconditional CFG row, :635-643), same RNG draw order (aug noise, then latents).
+Hot loop (:689-725) on the GPU: per step ONE U-Net forward on the persistent fp16 channels-last input buffer
+[2*T*h*w, 64] plus ONE fused kernel (CFG combine + Euler v-prediction step + scale_model_input + rewrite of the 4 noisy
+channels of the next input); the 14 conditioning channels are written once per clip.
+
+Scope: the temporal VAE (N1) and the CLIP image encoder (N2) are third-party models outside the hot
+path; they are duck-typed components here (`vae.encode(x).latent_dist.mode()`, `vae.decode(z, num_frames=k).sample`,
+`image_encoder(x).image_embeds`).  When they are not supplied, pass `image_latents=` ([1, 1+T, 4, h, w], unscaled VAE
+mode, before CFG duplication) and `image_embeddings=` ([1,1,1024]) and use output_type="latent".  `image_noise=` injects
+the augmentation noise draw (SURVEY.md §7 RNG parity) -- all three extra kwargs default to None = reference behaviour.
+"""
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+from .scheduler import EulerDiscreteScheduler
+from .unet import CPAD_IN
+
+
+def _append_dims(x, target_dims):
+    """pipeline_evoworld.py:128-133"""
+    d = target_dims - x.ndim
+    if d < 0:
+        raise ValueError(f"input has {x.ndim} dims but target_dims is {target_dims}, which is less")
+    return x[(...,) + (None,) * d]
+
+
+class StableVideoDiffusionPipelineOutput(SimpleNamespace):
+    pass
+
+
+class StableVideoDiffusionPipeline:
+    def __init__(self, unet, scheduler=None, vae=None, image_encoder=None, feature_extractor=None):
+        self.unet, self.vae, self.image_encoder, self.feature_extractor = unet, vae, image_encoder, feature_extractor
+        self.scheduler = scheduler or EulerDiscreteScheduler()
+        self.vae_scale_factor = 8 if vae is None else 2 ** (len(vae.config.block_out_channels) - 1)
+        self._device = unet.device or torch.device("cuda")
+        self._progress = {}
+
+    @classmethod
+    def from_pretrained(cls, path=None, unet=None, **kw):
+        """The reference builds the pipeline from a diffusers folder and injects its own unet
+        (unified_loop_consistency.py:193-197).  VAE / CLIP loading is a 'next' row; pass them via kw if available."""
+        if unet is None:
+            raise ValueError("pass unet= (evoworld_amd.unet.UNetSpatioTemporalConditionModel)")
+        return cls(unet=unet, scheduler=kw.get("scheduler"), vae=kw.get("vae"), image_encoder=kw.get("image_encoder"),
+                   feature_extractor=kw.get("feature_extractor"))
+
+    def to(self, device=None, dtype=None):
+        return self
+
+    def set_progress_bar_config(self, **kw):
+        self._progress = kw
+
+    @property
+    def _execution_device(self):
+        return self._device
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def do_classifier_free_guidance(self):
+        g = self._guidance_scale
+        return g > 1 if isinstance(g, (int, float)) else bool(g.max() > 1)
+
+    @property
+    def num_timesteps(self):
+        return self._num_timesteps
+
+    def check_inputs(self, image, height, width):
+        if not isinstance(image, torch.Tensor):
+            raise ValueError(f"`image` has to be a torch.Tensor on this path but is {type(image)}")
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+
+    def _get_add_time_ids(self, fps, motion_bucket_id, noise_aug_strength, dtype, batch_size, num_videos_per_prompt, cfg):
+        add_time_ids = [fps, motion_bucket_id, noise_aug_strength]
+        passed = self.unet.config.addition_time_embed_dim * len(add_time_ids)
+        expected = self.unet.add_embedding.linear_1.in_features
+        if expected != passed:
+            raise ValueError(f"Model expects an added time embedding vector of length {expected}, but a vector of {passed} "
+                             "was created. The model has an incorrect config.")
+        ids = torch.tensor([add_time_ids], dtype=dtype).repeat(batch_size * num_videos_per_prompt, 1)
+        return torch.cat([ids, ids]) if cfg else ids
+
+    def prepare_latents(self, batch_size, num_frames, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        shape = (batch_size, num_frames, 4, height // self.vae_scale_factor, width // self.vae_scale_factor)  # :413-420
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective "
+                             f"batch size of {batch_size}.")
+        if latents is None:
+            gdev = generator.device if isinstance(generator, torch.Generator) else device
+            latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
+        else:
+            latents = latents.to(device)
+        return latents * self.scheduler.init_noise_sigma
+
+    # ------------------------------------------------------------------ the hot loop
+    def denoise(self, latents, conditional_latents, image_embeddings, added_time_ids, guidance, num_inference_steps,
+                callback=None):
+        """latents fp32 [1,T,4,h,w] (already scaled by init_noise_sigma); conditional_latents fp32 [2,T,14,h,w];
+        image_embeddings [2,1,X]; added_time_ids [2,3]; guidance fp32 [T].  Returns final latents fp32 [1,T,4,h,w]."""
+        dev = self._device
+        _, T, _, h, w = latents.shape
+        ncond = conditional_latents.shape[2]
+        if 4 + ncond != self.unet.config.in_channels:
+            raise ValueError(f"4 + {ncond} conditioning channels != unet in_channels {self.unet.config.in_channels}")
+        sig = self.scheduler.sigmas
+        ts = self.scheduler.timesteps
+        lat = latents[0].to(device=dev, dtype=torch.float32).contiguous().clone()
+        x_in = torch.zeros(2 * T * h * w, CPAD_IN, dtype=torch.float16, device=dev)
+        ops.nchw_f32_to_nhwc_f16(conditional_latents.to(device=dev, dtype=torch.float32).reshape(2 * T, ncond, h, w).contiguous(),
+                                 x_in, CPAD_IN, c_off=4)
+        s0 = float(sig[0])
+        for half in range(2):  # latents duplicated on both CFG rows, scale_model_input for step 0 (:691-692)
+            ops.nchw_f32_to_nhwc_f16(lat, x_in[half * T * h * w:], CPAD_IN, c_off=0, scale=1.0 / (s0 * s0 + 1.0) ** 0.5)
+        guidance = guidance.to(device=dev, dtype=torch.float32).contiguous()
+        ehs = image_embeddings.to(dev)
+        ids = added_time_ids.to(dev)
+        for i in range(num_inference_steps):
+            eps = self.unet.forward_nhwc(x_in, ts[i], ehs, ids, 2, T, h, w)
+            ops.euler_cfg_step(eps, eps.shape[-1], lat, guidance, float(sig[i]), float(sig[i + 1]), x_in, CPAD_IN, T, h, w)
+            if callback is not None:
+                callback(i, ts[i], lat)
+        return lat[None]
+
+    @torch.no_grad()
+    def __call__(self, image, height=576, width=1024, num_frames=None, num_inference_steps=25, sigmas=None,
+                 min_guidance_scale=1.0, max_guidance_scale=3.0, fps=7, motion_bucket_id=127, noise_aug_strength=0.02,
+                 decode_chunk_size=None, num_videos_per_prompt=1, generator=None, latents=None, output_type="pil",
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs=["latents"], return_dict=True,
+                 plucker_embedding=None, memorized_plucker_embedding=None, memorized_pixel_values=None, mask_mem=False,
+                 image_latents=None, image_embeddings=None, image_noise=None):
+        dev = self._device
+        height = height or self.unet.config.sample_size * self.vae_scale_factor
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        num_frames = num_frames if num_frames is not None else self.unet.config.num_frames
+        decode_chunk_size = decode_chunk_size if decode_chunk_size is not None else num_frames
+        if sigmas is not None:
+            raise NotImplementedError("custom sigmas are not supported (the reference never passes them)")
+        if num_videos_per_prompt != 1:
+            raise NotImplementedError("num_videos_per_prompt != 1 is not used by the reference callers")
+        self.check_inputs(image, height, width)
+        if plucker_embedding is None:
+            raise ValueError("plucker_embedding [1,T,6,h,w] is required (evoworld conditioning)")
+        batch_size = image.shape[0]
+        if batch_size != 1:
+            raise NotImplementedError("one clip per call (the reference callers pass batch 1); shard clips across ranks")
+        self._guidance_scale = max_guidance_scale
+        cfg = self.do_classifier_free_guidance
+
+        # --- 3/4. image embedding + VAE latents of [first frame | memory frames]  (:570-623)
+        if image_latents is None or image_embeddings is None:
+            if self.vae is None or self.image_encoder is None:
+                raise ValueError("no vae / image_encoder component: pass image_latents= and image_embeddings= "
+                                 "(VAE and CLIP are 'next' rows, SURVEY.md §8f N1/N2)")
+            img = torch.cat([image.unsqueeze(1), memorized_pixel_values], dim=1).to(dev)   # :570
+            img = img / 2.0 + 0.5                                                           # :579
+            image_embeddings = self.image_encoder(img[:, 0]).image_embeds.unsqueeze(1)
+            flat = img.flatten(0, 1) * 2.0 - 1.0                                            # VideoProcessor.preprocess
+            noise = image_noise if image_noise is not None else torch.randn(
+                flat.shape, generator=generator, device=(generator.device if isinstance(generator, torch.Generator) else dev),
+                dtype=flat.dtype)
+            flat = flat + noise_aug_strength * noise.to(dev)                                 # :599-600
+            image_latents = self.vae.encode(flat).latent_dist.mode().reshape(1, -1, 4, height // 8, width // 8)
+        image_latents = image_latents.to(device=dev, dtype=torch.float32).clone()
+        image_embeddings = image_embeddings.to(device=dev, dtype=torch.float32)
+        if image_latents.shape[1] != num_frames + 1:
+            raise ValueError(f"memory frames ({image_latents.shape[1] - 1}) must equal num_frames ({num_frames})")  # :643
+        if cfg:                                                                              # :297-303, :320-326
+            image_embeddings = torch.cat([torch.zeros_like(image_embeddings), image_embeddings])
+            image_latents = torch.cat([torch.zeros_like(image_latents), image_latents])
+        else:
+            image_embeddings = torch.cat([image_embeddings, image_embeddings])
+            image_latents = torch.cat([image_latents, image_latents])
+        if mask_mem:
+            image_latents[:, 1:] = 0                                                         # :629-631
+        plucker = plucker_embedding.to(device=dev, dtype=torch.float32)
+        plucker = torch.cat([plucker, plucker], dim=0)                                       # :635 (dup, not zeroed)
+        first = image_latents[:, 0:1].repeat(1, num_frames, 1, 1, 1)
+        conditional_latents = torch.cat([first, image_latents[:, 1:], plucker], dim=2)       # :642-643
+
+        # --- 5-8. ids, timesteps, latents, guidance  (:646-682)
+        added_time_ids = self._get_add_time_ids(fps - 1, motion_bucket_id, noise_aug_strength, torch.float32, 1, 1, True)
+        self.scheduler.set_timesteps(num_inference_steps, device="cpu")
+        latents = self.prepare_latents(1, num_frames, self.unet.config.in_channels, height, width, torch.float32, dev,
+                                       generator, latents)
+        if cfg:
+            guidance = torch.linspace(min_guidance_scale, max_guidance_scale, num_frames)
+        else:
+            guidance = torch.ones(num_frames)      # both rows carry the conditional inputs -> e == cond prediction
+        self._guidance_scale = _append_dims(guidance.unsqueeze(0), latents.ndim)
+        self._num_timesteps = num_inference_steps
+
+        cb = None
+        if callback_on_step_end is not None:
+            def cb(i, t, lat):
+                out = callback_on_step_end(self, i, t, {"latents": lat[None]})
+                if out and "latents" in out and out["latents"] is not lat[None]:
+                    raise NotImplementedError("callbacks that replace latents are not supported on the fused path")
+        latents = self.denoise(latents, conditional_latents, image_embeddings, added_time_ids, guidance, num_inference_steps, cb)
+
+        if output_type != "latent":
+            if self.vae is None:
+                raise ValueError("output_type != 'latent' needs a vae component")
+            frames = self.decode_latents(latents, num_frames, decode_chunk_size)
+            frames = self._postprocess(frames, output_type)
+        else:
+            frames = latents
+        if not return_dict:
+            return frames
+        return StableVideoDiffusionPipelineOutput(frames=frames)
+
+    def decode_latents(self, latents, num_frames, decode_chunk_size=14):
+        latents = latents.flatten(0, 1) / self.vae.config.scaling_factor                     # :360-362
+        frames = [self.vae.decode(latents[i:i + decode_chunk_size], num_frames=latents[i:i + decode_chunk_size].shape[0]).sample
+                  for i in range(0, latents.shape[0], decode_chunk_size)]
+        frames = torch.cat(frames, dim=0)
+        return frames.reshape(-1, num_frames, *frames.shape[1:]).permute(0, 2, 1, 3, 4).float()
+
+    @staticmethod
+    def _postprocess(frames, output_type):
+        vid = (frames / 2 + 0.5).clamp(0, 1)                                                 # [B,C,T,H,W]
+        if output_type == "pt":
+            return vid.permute(0, 2, 1, 3, 4)
+        arr = (vid.permute(0, 2, 3, 4, 1).cpu().numpy() * 255).round().astype("uint8")
+        if output_type == "np":
+            return arr
+        from PIL import Image
+        return [[Image.fromarray(f) for f in clip] for clip in arr]

@@ -474,7 +474,7 @@ class UNetSpatioTemporalConditionModel:
         return ops.linear(hb, d["pow"], d["pob"], r1=x, ld_r1=C)
 
     # ---------------- forward ----------------
-    def forward_nhwc(self, x, timestep, encoder_hidden_states, added_time_ids, B, T, H, W_):
+    def forward_nhwc(self, x, timestep, encoder_hidden_states, added_time_ids, B, T, H, W_, taps=None):
         """x: fp16 [B*T*H*W, 64] channels-last (18 real channels, zero padded) -> fp16 [B*T*H*W, 4]."""
         cfg, Wt = self._cfg, self.w
         dev = x.device
@@ -494,8 +494,10 @@ class UNetSpatioTemporalConditionModel:
         cvecs = ops.linear(ehs, Wt["cv_w"], Wt["cv_b"])               # all 32 cross-attention vectors at once
 
         h = self._conv3x3(x, None, *Wt["conv_in"], N, H, W_, H, W_)
+        if taps is not None:
+            taps["conv_in"] = (h, H, W_)
         skips = [(h, H, W_)]
-        for blk in self.arch.downs:
+        for bi, blk in enumerate(self.arch.downs):
             for l, r in enumerate(blk.res):
                 h = self._resblock(r, [h], tembs, B, T, H, W_)
                 if blk.attn:
@@ -506,11 +508,15 @@ class UNetSpatioTemporalConditionModel:
                 h = self._conv3x3(h, None, w, b, N, H, W_, H // 2, W_ // 2, stride=2)
                 H, W_ = H // 2, W_ // 2
                 skips.append((h, H, W_))
+            if taps is not None:
+                taps[f"down{bi}"] = (h, H, W_)
         m = self.arch.mid
         h = self._resblock(m.res[0], [h], tembs, B, T, H, W_)
         h = self._transformer(m.attn[0], h, cvecs, B, T, H, W_)
         h = self._resblock(m.res[1], [h], tembs, B, T, H, W_)
-        for blk in self.arch.ups:
+        if taps is not None:
+            taps["mid"] = (h, H, W_)
+        for bi, blk in enumerate(self.arch.ups):
             for l, r in enumerate(blk.res):
                 sk, sh, sw = skips.pop()
                 assert (sh, sw) == (H, W_)
@@ -521,11 +527,13 @@ class UNetSpatioTemporalConditionModel:
                 w, b = Wt[blk.up.p]
                 h = self._conv3x3(h, None, w, b, N, H, W_, 2 * H, 2 * W_, upsample=1)
                 H, W_ = 2 * H, 2 * W_
+            if taps is not None:
+                taps[f"up{bi}"] = (h, H, W_)
         hn = ops.groupnorm([h], Wt["no_g"], Wt["no_b"], N, H * W_, 1e-5, True)
         return self._conv3x3(hn, None, *Wt["conv_out"], N, H, W_, H, W_)
 
     @torch.no_grad()
-    def __call__(self, sample, timestep, encoder_hidden_states, added_time_ids, return_dict=True):
+    def __call__(self, sample, timestep, encoder_hidden_states, added_time_ids, return_dict=True, taps=None):
         if self.w is None:
             raise RuntimeError("weights not loaded")
         if sample.ndim != 5 or sample.shape[2] != self._cfg["in_channels"]:
@@ -536,7 +544,7 @@ class UNetSpatioTemporalConditionModel:
         x = torch.zeros(B * T * H * W_, CPAD_IN, dtype=torch.float16, device=self.device)
         ops.nchw_f32_to_nhwc_f16(sample.to(device=self.device, dtype=torch.float32).reshape(B * T, C, H, W_).contiguous(),
                                  x, CPAD_IN)
-        eps = self.forward_nhwc(x, timestep, encoder_hidden_states, added_time_ids, B, T, H, W_)
+        eps = self.forward_nhwc(x, timestep, encoder_hidden_states, added_time_ids, B, T, H, W_, taps=taps)
         oc = self._cfg["out_channels"]
         out = ops.nhwc_f16_to_nchw_f32(eps, B * T, oc, H, W_, oc).reshape(B, T, oc, H, W_)
         if not return_dict:

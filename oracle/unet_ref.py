@@ -394,5 +394,5 @@ class UNetSpatioTemporalConditionModelRef(nn.Module):
 def tiny_config():
     """A shrunken config with the same topology (4 levels, same block types) for CPU-speed tests."""
     return dict(in_channels=18, out_channels=4, block_out_channels=(64, 128, 256, 256),
-                addition_time_embed_dim=32, projection_class_embeddings_input_dim=96,
+                addition_time_embed_dim=64, projection_class_embeddings_input_dim=192,
                 layers_per_block=2, cross_attention_dim=64, num_attention_heads=(1, 2, 4, 4), num_frames=4)

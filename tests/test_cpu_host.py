@@ -1,0 +1,94 @@
+"""-m 'not gpu': host logic + the C-ABI library loads and exports every symbol include/evoworld_hip.h declares."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from evoworld_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "evoworld_hip.h")).read()
+    declared = set(re.findall(r"\b(ew_[a-z0-9_]+)\s*\(", hdr)) - {"ew_gemm_args"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert lib.ew_abi_version() == _lib.ABI_VERSION
+
+
+def test_gemm_args_struct_matches_header():
+    from evoworld_amd._lib import GemmArgs
+    hdr = open(os.path.join(ROOT, "include", "evoworld_hip.h")).read()
+    body = hdr[hdr.index("typedef struct ew_gemm_args {"):hdr.index("} ew_gemm_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        parts = decl.replace("*", " ").split(",")
+        names.append(parts[0].split()[-1])
+        names += [p.strip() for p in parts[1:]]
+    assert names == [f[0] for f in GemmArgs._fields_]
+
+
+def test_ops_refuse_cpu_tensors():
+    from evoworld_amd import ops
+    from evoworld_amd._lib import EvoWorldHipError
+    with pytest.raises(EvoWorldHipError):
+        ops.linear(torch.zeros(4, 64, dtype=torch.float16), torch.zeros(4, 64, dtype=torch.float16))
+
+
+def test_param_spec_matches_oracle_state_dict():
+    from evoworld_amd.unet import DEFAULT_CONFIG, param_spec
+    from oracle.unet_ref import UNetSpatioTemporalConditionModelRef, tiny_config
+    for cfg in (tiny_config(), {}):
+        with torch.device("meta"):
+            ref = UNetSpatioTemporalConditionModelRef(**cfg)
+        sd = ref.state_dict()
+        spec = param_spec({**DEFAULT_CONFIG, **cfg})
+        assert list(spec.keys()) == list(sd.keys())
+        for k, (shape, _) in spec.items():
+            assert tuple(sd[k].shape) == tuple(shape), k
+    # the public SVD-XT U-Net has 1,524,623,082 parameters with in_channels=8; EvoWorld widens conv_in to 18
+    n = sum(int(np.prod(s)) for s, _ in param_spec(DEFAULT_CONFIG).values())
+    assert n == 1_524_623_082 + (18 - 8) * 320 * 9
+
+
+def test_scheduler_known_answers():
+    from evoworld_amd.scheduler import EulerDiscreteScheduler
+    s = EulerDiscreteScheduler()
+    s.set_timesteps(25)
+    sig = s.sigmas.numpy()
+    np.testing.assert_allclose(sig[:4], [700.0, 545.72925, 421.56912, 322.45367], rtol=2e-6)   # SURVEY.md §8a S1 KAT
+    np.testing.assert_allclose(sig[-4:], [0.02480258, 0.0078825, 0.002, 0.0], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(s.timesteps.numpy()[[0, 1, 2, -1]], [1.63777, 1.5755308, 1.510996, -1.553652], rtol=2e-6)
+    assert abs(s.init_noise_sigma - 700.000714) < 1e-5
+    # v-prediction step == the c_skip / c_out form of the reference's training loss (train_evoworld.py:698-700)
+    g = torch.Generator().manual_seed(0)
+    x, v = torch.randn(3, 4, generator=g) * 500, torch.randn(3, 4, generator=g)
+    out = s.step(v, s.timesteps[0], x)
+    sg = s.sigmas[0]
+    c_skip, c_out = 1 / (sg ** 2 + 1), -sg / (sg ** 2 + 1) ** 0.5
+    assert torch.allclose(out.pred_original_sample, c_skip * x + c_out * v, rtol=1e-6, atol=1e-6)
+
+
+def test_geometry_and_rays_golden(golden_dir):
+    from evoworld_amd.geometry import xyz_euler_to_four_by_four_matrix_batch, xyz_euler_to_three_by_four_matrix_batch
+    from evoworld_amd.plucker import equirectangular_to_ray
+    g = np.load(f"{golden_dir}/plucker.npz")
+    rp = torch.tensor(g["rand_poses"])
+    for rel, k3, k4 in ((False, "rand_c2w_abs", "rand_c2w4_abs"), (True, "rand_c2w_rel", "rand_c2w4_rel")):
+        np.testing.assert_allclose(xyz_euler_to_three_by_four_matrix_batch(rp, relative=rel).numpy(), g[k3], atol=1e-6)
+        np.testing.assert_allclose(xyz_euler_to_four_by_four_matrix_batch(rp, relative=rel).numpy(), g[k4], atol=1e-6)
+    for tag in ("ps01", "ps10"):
+        c2w = xyz_euler_to_three_by_four_matrix_batch(torch.tensor(g[f"cam_{tag}"]), relative=True)
+        np.testing.assert_allclose(c2w.numpy(), g[f"c2w_{tag}"], atol=1e-6)
+    np.testing.assert_allclose(g["c2w_ps01"][24], [[0.691786, 0, 0.722103, 0.721130], [0, 1, 0, 0],
+                                                   [-0.722103, 0, 0.691786, 0.692799]], atol=2e-6)
+    np.testing.assert_allclose(equirectangular_to_ray(72, 128).astype(np.float32), g["rays_72x128"], atol=1e-7)
+    np.testing.assert_allclose(equirectangular_to_ray(8, 16).astype(np.float32), g["rays_8x16"], atol=1e-7)

@@ -1,0 +1,76 @@
+"""-m gpu: the HIP U-Net (through the C ABI) against the fp32 CPU oracle on the same seeded weights/inputs.
+Tolerance (stated): the product computes in fp16 storage / fp32 accumulation; against the fp32 oracle run on the
+same fp16-representable checkpoint the end-to-end rel-L2 of one U-Net forward must be <= 5e-3 (tiny config),
+each tapped block output <= 5e-3.  BASELINE.json's 1e-3 target is tracked in DESIGN.md (measured value printed)."""
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(cfg, B, T, h, w, seed=0):
+    from evoworld_amd.unet import UNetSpatioTemporalConditionModel, random_state_dict
+    from oracle.unet_ref import UNetSpatioTemporalConditionModelRef
+    full = dict(cfg)
+    sd = {k: v.half().float() for k, v in random_state_dict({**__import__("evoworld_amd.unet", fromlist=["DEFAULT_CONFIG"]).DEFAULT_CONFIG, **full}, seed).items()}
+    ref = UNetSpatioTemporalConditionModelRef(**cfg).eval()
+    missing, unexpected = ref.load_state_dict(sd, strict=True), None
+    m = UNetSpatioTemporalConditionModel(**cfg).load_state_dict(sd, device="cuda")
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(B, T, cfg["in_channels"], h, w, generator=g)
+    ehs = torch.randn(B, 1, cfg["cross_attention_dim"], generator=g)
+    ehs[0] = 0  # CFG uncond row
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * B)
+    return m, ref, x, ehs, ids
+
+
+def test_unet_tiny_vs_oracle():
+    from oracle.unet_ref import tiny_config
+    cfg = tiny_config()
+    B, T, h, w = 2, 4, 16, 32
+    m, ref, x, ehs, ids = _setup(cfg, B, T, h, w)
+    t = torch.tensor(1.6377)
+    rt = {}
+    want = ref(x, t, ehs, ids, taps=rt)
+    gt = {}
+    got = m(x.cuda(), t, ehs.cuda(), ids.cuda(), return_dict=False, taps=gt)[0]
+    worst = 0.0
+    for k, (ten, H, W) in gt.items():
+        a = ten.float().reshape(B * T, H, W, -1).permute(0, 3, 1, 2).cpu()
+        e = rel_l2(a, rt[k])
+        print(f"tap {k:8s} rel-L2 {e:.2e}")
+        worst = max(worst, e)
+    e = rel_l2(got.cpu(), want)
+    print(f"unet tiny forward rel-L2 {e:.3e}")
+    assert torch.isfinite(got).all()
+    assert worst < 5e-3 and e < 5e-3
+
+
+def test_unet_tiny_T25_ragged_spatial():
+    """T=25 (the real frame count) and a latent size whose deepest level has S=8 (< one KV tile)."""
+    from oracle.unet_ref import tiny_config
+    cfg = tiny_config()
+    cfg["num_frames"] = 25
+    B, T, h, w = 2, 25, 16, 32
+    m, ref, x, ehs, ids = _setup(cfg, B, T, h, w, seed=3)
+    t = torch.tensor(-0.7)
+    want = ref(x, t, ehs, ids)
+    got = m(x.cuda(), t, ehs.cuda(), ids.cuda(), return_dict=False)[0]
+    e = rel_l2(got.cpu(), want)
+    print(f"unet tiny T=25 forward rel-L2 {e:.3e}")
+    assert e < 5e-3
+
+
+def test_unet_dead_cross_attention_identity():
+    """The reference executes the single-token cross attention in full; the folded form must agree (oracle both ways)."""
+    from oracle.unet_ref import UNetSpatioTemporalConditionModelRef, tiny_config
+    ref = UNetSpatioTemporalConditionModelRef(**tiny_config()).eval()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 2, 18, 8, 16, generator=g)
+    ehs = torch.randn(2, 1, 64, generator=g)
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
+    a = ref(x, torch.tensor(0.3), ehs, ids)
+    b = ref(x, torch.tensor(0.3), ehs, ids, exec_dead_cross_attn=True)
+    assert rel_l2(a, b) < 1e-5
