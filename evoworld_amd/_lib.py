@@ -5,6 +5,9 @@ loudly -- there is no CPU / PyTorch fallback for the product path.
 """
 import ctypes
 import os
+
+import torch  # noqa: F401  MUST precede the CDLL below: torch bundles its own libamdhip64.so.7; loading ours first
+#                     would pull /opt/rocm's copy and leave two HIP runtimes in the process ("no ROCm-capable device").
 from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
