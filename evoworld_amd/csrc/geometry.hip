@@ -183,9 +183,10 @@ extern "C" ew_status ew_depth_unproject(const float* depth, const float* extr, c
 
 extern "C" ew_status ew_splat_cubemap(const float* xyz, size_t npts, const float* w2c, unsigned long long* zbuf, int V,
                                       int res, float fx, float fy, float cx, float cy, float z_near, void* stream) {
-    EW_REQUIRE(xyz && w2c && zbuf && V > 0 && res > 0, "ew_splat_cubemap: bad args");
+    EW_REQUIRE(w2c && zbuf && V > 0 && res > 0, "ew_splat_cubemap: bad args");
     EW_REQUIRE(npts < 0xffffffffULL, "ew_splat_cubemap: npts must fit 32 bits");
-    if (npts == 0) return EW_OK;
+    if (npts == 0) return EW_OK;   // empty cloud: z-buffers stay at their init value
+    EW_REQUIRE(xyz, "ew_splat_cubemap: null xyz");
     hipLaunchKernelGGL(splat_kernel, dim3(grid_for((long long)npts * V)), dim3(256), 0, (hipStream_t)stream, xyz,
                        (long long)npts, w2c, zbuf, V, res, fx, fy, cx, cy, z_near);
     return ew_check_launch("ew_splat_cubemap");
