@@ -1,0 +1,30 @@
+// gemm_common.h -- parameter block shared by the GEMM kernel generations.
+#pragma once
+#include "common.h"
+
+struct GemmP {
+    const f16* a;
+    const f16* a2;
+    const f16* w;
+    const f16* bias;
+    const f16* rowbias;
+    const f16* r1;
+    const f16* r2;
+    f16* out;
+    const f16* zero_page;
+    int M, N, K;
+    int c1, c2, lda, lda2, ld_out, ld_r1, ld_r2, ld_rowbias;
+    int mode, n_img, h_in, w_in, h_out, w_out, stride, upsample;
+    int tB, tT, tP;
+    int rows_per_group, act;
+    float c_acc, c_r1, c_r2;
+    int tiles_m, tiles_n;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const f16* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+

@@ -18,35 +18,10 @@
 //     current tile.
 //   * XCD-aware tile order: consecutive tile ids (N fastest) land on the same XCD so the A panel is an L2 hit.
 //   * epilogue: accumulators -> wave-private LDS patch -> row-major float4 -> fused ops -> 8-byte fp16 stores.
-#include "common.h"
+#include "gemm_common.h"
+#include <stdlib.h>
 
 namespace {
-
-struct GemmP {
-    const f16* a;
-    const f16* a2;
-    const f16* w;
-    const f16* bias;
-    const f16* rowbias;
-    const f16* r1;
-    const f16* r2;
-    f16* out;
-    const f16* zero_page;
-    int M, N, K;
-    int c1, c2, lda, lda2, ld_out, ld_r1, ld_r2, ld_rowbias;
-    int mode, n_img, h_in, w_in, h_out, w_out, stride, upsample;
-    int tB, tT, tP;
-    int rows_per_group, act;
-    float c_acc, c_r1, c_r2;
-    int tiles_m, tiles_n;
-};
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-__device__ __forceinline__ void glds16(const f16* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
-}
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
@@ -288,6 +263,17 @@ ew_status launch(const GemmP& p, hipStream_t s) {
 
 }  // namespace
 
+ew_status ew_gemm2_dispatch(const GemmP& p, hipStream_t s);   // gemm2_f16.hip
+static int g_gemm_gen = -1;
+extern "C" void ew_set_gemm_generation(int gen) { g_gemm_gen = gen; }
+extern "C" int ew_get_gemm_generation(void) {
+    if (g_gemm_gen < 0) {
+        const char* e = getenv("EW_GEMM_GEN");
+        g_gemm_gen = e ? atoi(e) : 2;
+    }
+    return g_gemm_gen;
+}
+
 extern "C" ew_status ew_gemm_f16(const ew_gemm_args* a, void* stream) {
     EW_REQUIRE(a != nullptr, "ew_gemm_f16: null args");
     EW_REQUIRE(a->a && a->w && a->out && a->zero_page, "ew_gemm_f16: null a/w/out/zero_page");
@@ -330,7 +316,8 @@ extern "C" ew_status ew_gemm_f16(const ew_gemm_args* a, void* stream) {
     p.rows_per_group = a->rows_per_group; p.act = a->act; p.c_acc = a->c_acc; p.c_r1 = a->c_r1; p.c_r2 = a->c_r2;
     p.tiles_m = p.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
-    // tile choice: every channel count of the U-Net is a multiple of 160 (320*k); GEGLU and odd sizes use 128
+    if (ew_get_gemm_generation() == 2) return ew_gemm2_dispatch(p, s);
+    // generation 1 tile choice: every channel count of the U-Net is a multiple of 160 (320*k); GEGLU and odd sizes use 128
     if (a->act != EW_ACT_GEGLU && a->N % 160 == 0) return launch<128, 160>(p, s);
     return launch<128, 128>(p, s);
 }

@@ -78,6 +78,10 @@ typedef struct ew_gemm_args {
 } ew_gemm_args;
 
 ew_status ew_gemm_f16(const ew_gemm_args* args, void* stream);
+/* Kernel generation behind ew_gemm_f16: 1 = 128x160 tile, 2 blocks/CU; 2 = persistent 3-stage ring (default; env
+ * EW_GEMM_GEN overrides).  Same arguments, same results to rounding; kept selectable for A/B measurements. */
+void ew_set_gemm_generation(int gen);
+int ew_get_gemm_generation(void);
 
 /* GroupNorm statistics + apply, channels-last fp16, over a (virtual) channel concat.
  * The normalised tensor has C_tot channels in `groups` groups; this call handles the C_src channels

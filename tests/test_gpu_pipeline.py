@@ -72,7 +72,7 @@ def models():
 @pytest.mark.parametrize("mask_mem", [False, True])
 def test_denoise_loop_vs_oracle(models, mask_mem):
     cfg, ref, unet, Pipe = models
-    T, h, w, steps = 4, 8, 16, 3
+    T, h, w, steps = 4, 16, 32, 3
     g = torch.Generator().manual_seed(5)
     lat0, il = torch.randn(1, T, 4, h, w, generator=g), torch.randn(1, T + 1, 4, h, w, generator=g)
     ehs, pl = torch.randn(1, 1, cfg["cross_attention_dim"], generator=g), torch.randn(1, T, 6, h, w, generator=g)
@@ -89,7 +89,7 @@ def test_full_call_surface_with_component_duck_types(models):
     """image -> CLIP / VAE duck types -> conditioning assembly (RNG order: aug noise, then latents; CPU generator as in
     navigator_evoworld.py:198) -> loop -> decode -> PIL frames."""
     cfg, ref, unet, Pipe = models
-    T, H, W, steps = 4, 64, 128, 2
+    T, H, W, steps = 4, 128, 256, 2
     g = torch.Generator().manual_seed(9)
     image = torch.rand(1, 3, H, W, generator=g) * 2 - 1
     memory = torch.rand(1, T, 3, H, W, generator=g) * 2 - 1
@@ -118,7 +118,7 @@ def test_full_call_surface_with_component_duck_types(models):
 def test_input_validation_matches_reference(models):
     cfg, ref, unet, Pipe = models
     pipe = Pipe(unet=unet)
-    pl = torch.zeros(1, 4, 6, 8, 16)
+    pl = torch.zeros(1, 4, 6, 8, 16)  # shapes only matter for validation
     with pytest.raises(ValueError):
         pipe(torch.zeros(1, 3, 60, 128), height=60, width=128, num_frames=4, plucker_embedding=pl,
              image_latents=torch.zeros(1, 5, 4, 8, 16), image_embeddings=torch.zeros(1, 1, 64))      # H % 8 != 0
