@@ -16,7 +16,7 @@ ABI_VERSION = 1
 
 # every symbol declared in include/evoworld_hip.h
 SYMBOLS = [
-    "ew_abi_version", "ew_last_error", "ew_gemm_f16", "ew_set_gemm_generation", "ew_get_gemm_generation", "ew_groupnorm_stats_f16", "ew_groupnorm_apply_f16",
+    "ew_abi_version", "ew_last_error", "ew_gemm_f16", "ew_set_gemm_generation", "ew_get_gemm_generation", "ew_set_gemm_debug", "ew_groupnorm_stats_f16", "ew_groupnorm_apply_f16",
     "ew_layernorm_f16", "ew_attn_spatial_f16", "ew_attn_temporal_f16", "ew_nchw_f32_to_nhwc_f16",
     "ew_nhwc_f16_to_nchw_f32", "ew_euler_cfg_step", "ew_plucker_embed", "ew_cube2equi_gather",
     "ew_depth_unproject", "ew_splat_cubemap", "ew_splat_resolve", "ew_equi2pers",
@@ -81,10 +81,14 @@ def load():
     lib.ew_set_gemm_generation.argtypes = [c_int]
     lib.ew_set_gemm_generation.restype = None
     lib.ew_get_gemm_generation.restype = c_int
+    lib.ew_set_gemm_debug.argtypes = [c_int]
+    lib.ew_set_gemm_debug.restype = None
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = c_int
+    if os.environ.get("EW_GEMM_DEBUG"):            # measurement switches (tools/experiments), never set in production
+        lib.ew_set_gemm_debug(int(os.environ["EW_GEMM_DEBUG"]))
     _lib = lib
     return lib
 

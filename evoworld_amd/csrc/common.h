@@ -29,8 +29,21 @@ ew_status ew_check_launch(const char* what);
 static inline int ew_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ float ew_silu(float x) { return x / (1.0f + __expf(-x)); }
-// exact (erf) GELU, as torch.nn.functional.gelu default (diffusers GEGLU)
-__device__ __forceinline__ float ew_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf GELU (torch.nn.functional.gelu default, diffusers GEGLU).  erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7,
+// i.e. below fp32 erff's own error after the fp16 output rounding): 2 transcendentals + ~10 VALU instead of libm's
+// ~50-instruction erff -- the GEGLU epilogue was costing as much as the K=320 MFMA loop (profiles/r01 notes).
+__device__ __forceinline__ float ew_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+    const float y = fmaf(-p * t, e, 1.0f);
+    return copysignf(y, x);
+}
+__device__ __forceinline__ float ew_gelu(float x) { return 0.5f * x * (1.0f + ew_erf(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

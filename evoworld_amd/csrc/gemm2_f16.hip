@@ -17,6 +17,7 @@
 //     and stores -- no LDS patch, which is what lets the ring keep streaming during the epilogue.
 // Same argument block, same addressing modes (dense / conv3x3 / temporal 3-tap, dual source, zero page) as gen 1.
 #include "gemm_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -37,28 +38,35 @@ __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 6) EW_WAIT_VMCNT(6);
     else if constexpr (N == 7) EW_WAIT_VMCNT(7);
     else if constexpr (N == 8) EW_WAIT_VMCNT(8);
-    else static_assert(N <= 8, "extend wait_vmcnt");
+    else if constexpr (N == 10) EW_WAIT_VMCNT(10);
+    else if constexpr (N == 14) EW_WAIT_VMCNT(14);
+    else if constexpr (N == 18) EW_WAIT_VMCNT(18);
+    else if constexpr (N == 19) EW_WAIT_VMCNT(19);
+    else static_assert(N < 0, "extend wait_vmcnt");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
-__global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmP p) {
+// EPI: compile-time epilogue operand set -- bit0 row-bias, bit1 residual r1, bit2 residual r2, bit3 GEGLU.  An operand
+// that is compiled in but absent at run time is read from the zero page with stride 0 (so a superset kernel is always valid).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, int EPI>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const GemmP p) {
+    constexpr int NW = WAVES_M * WAVES_N;                  // 8 waves, 1 workgroup/CU  -or-  4 waves, 2 workgroups/CU
     constexpr int BK = 64;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int FM = WM / 16, FN = WN / 16;
     constexpr int A_GROUPS = BM / 8, B_GROUPS = BN / 8;
-    constexpr int GA = A_GROUPS / 8;                       // A row-groups per wave (A_GROUPS is a multiple of 8)
-    constexpr int GB = (B_GROUPS + 7) / 8;                 // W row-groups per wave (the last may be partial)
-    constexpr int GB_FULL = B_GROUPS / 8;                  // W row-groups every wave owns
+    constexpr int GA = A_GROUPS / NW;                      // A row-groups per wave (A_GROUPS is a multiple of NW)
+    constexpr int GB = (B_GROUPS + NW - 1) / NW;           // W row-groups per wave (the last may be partial)
+    constexpr int GB_FULL = B_GROUPS / NW;                 // W row-groups every wave owns
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int A_BYTES = BM * 128;
-    static_assert(WAVES_M * WAVES_N == 8 && WM == 64, "8 waves, 64-row wave tiles");
+    static_assert((NW == 8 || NW == 4) && WM == 64 && A_GROUPS % NW == 0 && (NSTAGE == 2 || NSTAGE == 3), "config");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
-    const bool has_tail = (GB > GB_FULL) && (wave + 8 * GB_FULL < B_GROUPS);   // owns the partial last W group
+    const bool has_tail = (GB > GB_FULL) && (wave + NW * GB_FULL < B_GROUPS);   // owns the partial last W group
     const int n_ld = GA + GB_FULL + (has_tail ? 1 : 0);                         // DMA instructions per K-tile (this wave)
 
     // ---- tile sequence of this persistent block: step i -> tile id i*G + (b%8)*(G/8) + b/8  (XCD-contiguous chunks)
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmP p) {
         const int m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
         for (int i = 0; i < GA; ++i) {
-            int m = m0 + (wave + 8 * i) * 8 + srow;
+            int m = m0 + (wave + NW * i) * 8 + srow;
             m = m < p.M ? m : p.M - 1;
             a_row[i] = m;
             if constexpr (MODE == EW_A_CONV3X3) {
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmP p) {
         }
 #pragma unroll
         for (int j = 0; j < GB; ++j) {
-            int n = n0 + (wave + 8 * j) * 8 + srow;
+            int n = n0 + (wave + NW * j) * 8 + srow;
             n = n < p.N ? n : p.N - 1;
             b_ptr[j] = p.w + (size_t)n * p.K + slot * 8;
         }
@@ -142,24 +150,33 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmP p) {
         }
         const int ch = second ? cc - p.c1 : cc;
 #pragma unroll
-        for (int i = 0; i < GA; ++i) glds16(a_src[i] + (a_ok[i] ? ch : 0), buf + (wave + 8 * i) * 1024);
+        for (int i = 0; i < GA; ++i) glds16(a_src[i] + (a_ok[i] ? ch : 0), buf + (wave + NW * i) * 1024);
         const size_t koff = (size_t)ld_kt * BK;
 #pragma unroll
-        for (int j = 0; j < GB_FULL; ++j) glds16(b_ptr[j] + koff, buf + A_BYTES + (wave + 8 * j) * 1024);
+        for (int j = 0; j < GB_FULL; ++j) glds16(b_ptr[j] + koff, buf + A_BYTES + (wave + NW * j) * 1024);
         if constexpr (GB > GB_FULL) {
-            if (has_tail) glds16(b_ptr[GB - 1] + koff, buf + A_BYTES + (wave + 8 * (GB - 1)) * 1024);
+            if (has_tail) glds16(b_ptr[GB - 1] + koff, buf + A_BYTES + (wave + NW * (GB - 1)) * 1024);
         }
         ld_cc += BK;
         if (ld_cc == C) { ld_cc = 0; ++ld_tap; }
         if (++ld_kt == nk) { ld_kt = 0; ++ld_i; }
     };
 
-    auto wait_landed = [&](bool more_in_flight) {   // own DMA of the NEXT K-tile landed; leave the newest tile in flight
-        if (!more_in_flight) { wait_vmcnt<0>(); return; }
-        if constexpr (GB > GB_FULL) {
-            if (has_tail) wait_vmcnt<GA + GB_FULL + 1>(); else wait_vmcnt<GA + GB_FULL>();
-        } else {
-            wait_vmcnt<GA + GB_FULL>();
+    // Output stores issued by this wave in one FULL-tile epilogue (exact instruction count: every store executes).
+    constexpr int NST = FM * ((((EPI & 8) ? 16 * (WN / 16) : 16 * (WN / 8)) + 63) / 64);   // 16-byte row-major stores
+    // own DMA of the NEXT K-tile landed; the newest K-tile (n_ld DMA instructions) stays in flight.  `stores_behind`:
+    // the NST output stores of the tile just finished were issued AFTER the DMA we wait for -- vmcnt counts in issue
+    // order, so they are allowed to stay in flight too and the wave does not stall on store acknowledgements.
+    auto wait_landed = [&](bool more_in_flight, bool stores_behind) {
+        if constexpr (NSTAGE == 2) { wait_vmcnt<0>(); return; }         // nothing newer than the tile we wait for
+        else {
+            if (!more_in_flight) { wait_vmcnt<0>(); return; }
+            if constexpr (GB > GB_FULL) {
+                if (has_tail) { if (stores_behind) wait_vmcnt<GA + GB_FULL + 1 + NST>(); else wait_vmcnt<GA + GB_FULL + 1>(); }
+                else { if (stores_behind) wait_vmcnt<GA + GB_FULL + NST>(); else wait_vmcnt<GA + GB_FULL>(); }
+            } else {
+                if (stores_behind) wait_vmcnt<GA + GB_FULL + NST>(); else wait_vmcnt<GA + GB_FULL>();
+            }
         }
     };
 
@@ -193,22 +210,38 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmP p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // D[n][m]
     };
 
-    // ---------------- prologue: two K-tiles in flight, first fragments in registers ----------------
-    stage(smem);
-    if (V > 1) stage(smem + STAGE);
-    wait_landed(V > 1);
+    if constexpr (NW == 4) {
+        // Two 4-wave workgroups share a CU.  Started together they stay in lock-step (same tile shape, same duration) and hit
+        // their store-bound epilogues at the same time; delaying the second half of the grid by ~half a tile makes one
+        // group's epilogue coincide with the other's MFMA phase.  (s_sleep 1 = 64 cycles; a K-tile is ~1300 cycles here.)
+        if ((p.dbg & 32) && blockIdx.x >= (gridDim.x >> 1))
+            for (int i = 0; i < nk * 10 + 16; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+    // ---------------- prologue: NSTAGE K-tiles requested, first fragments in registers ----------------
+    // Ring rule: barrier(v) publishes stream position v+1 and frees slot v%NSTAGE; the DMA of position v+NSTAGE is issued
+    // right after it -- except when position v ends an output tile: then the freed slot first hosts the epilogue patches
+    // and the DMA is issued after the epilogue's closing barrier.
+    int staged = 0;                                  // stream positions whose DMA has been issued
+    for (; staged < NSTAGE && staged < V; ++staged) stage(smem + staged * STAGE);
+    if (V > 1) {
+        if constexpr (NSTAGE == 3) { if (V > 2) wait_landed(true, false); else { wait_vmcnt<0>(); } }
+        else wait_vmcnt<0>();
+    } else {
+        wait_vmcnt<0>();
+    }
+    if constexpr (NSTAGE == 2) { /* both tiles waited: simplest, once per launch */ }
     EW_COMPILER_FENCE();
     __builtin_amdgcn_s_barrier();
     EW_COMPILER_FENCE();
     read_frags(smem, so0, af0, bf0);
 
     int cur_i = 0, cur_kt = 0;
+    bool stores_behind = false;                      // a full-tile epilogue's stores are newer than the DMA waited next
     int s_cur = 0;                                   // ring slot of stream position v
     for (int v = 0; v < V; ++v) {
-        const int s_nxt = s_cur == 2 ? 0 : s_cur + 1;
-        const int s_nn = s_nxt == 2 ? 0 : s_nxt + 1;
+        const int s_nxt = s_cur == NSTAGE - 1 ? 0 : s_cur + 1;
         const char* cur = smem + s_cur * STAGE;
-        if (v + 2 < V) stage(smem + s_nn * STAGE);   // slot of v-1: every wave passed barrier(v-1) after its last read
+        const bool tile_end = cur_kt == nk - 1;
         // ---- half-step 0: MFMA on k[0,32), fetch fragments of k[32,64)
         EW_WAIT_LGKM0();   // af0/bf0 (read one half-step ago) have landed: free, and it lets the MFMAs below start
                            // without waiting for the reads issued next (hipcc otherwise emits lgkmcnt(0) after them)
@@ -218,15 +251,18 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmP p) {
         // ---- publish K-tile v+1.  Unconditional (also on the last position, where the fragments read from the ring are
         // stale and never used): a conditional here makes hipcc put a conservative lgkmcnt(0) at the join, in front of
         // the half-step-1 MFMAs, which would expose the LDS latency of the reads just issued.
-        wait_landed(v + 2 < V);
+        wait_landed(v + 2 < staged, stores_behind);
+        stores_behind = false;
         EW_WAIT_LGKM0();
         EW_COMPILER_FENCE();
         __builtin_amdgcn_s_barrier();
         EW_COMPILER_FENCE();
         read_frags(smem + s_nxt * STAGE, so0, af0, bf0);
+        if (!tile_end && staged < V) { stage(smem + s_cur * STAGE); ++staged; }   // slot of v is free from here on
         __builtin_amdgcn_sched_barrier(0);
         // ---- half-step 1
         mma(af1, bf1);
+        const int s_prev = s_cur;
         s_cur = s_nxt;
         if (++cur_kt == nk) {
             // ------------------------- epilogue of output tile cur_i (registers only) -------------------------
@@ -234,130 +270,182 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(const GemmP p) {
             const int id = cur_i * G + seq0;
             ++cur_i;
             const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
-            const int mb = tm * BM + wm * WM + frow;
-            const int nb = tn * BN + wn * WN + fks * 4;
-            if (p.act != EW_ACT_GEGLU) {
-                // Branch-free operand fetch: an absent bias / row-bias / residual reads a zero page with stride 0, so the
-                // compiler sees straight-line code and emits COUNTED vmcnt waits (a uniform branch per operand made it
-                // fall back to vmcnt(0) after every store).  Loads of column fragment j+1 are issued before the stores
-                // of fragment j (software pipeline), so a wait never has to drain the stores.
+            // every store instruction of this wave executes iff its whole wave tile is inside the matrix
+            stores_behind = (tm * BM + wm * WM + WM <= p.M) && (tn * BN + wn * WN + WN <= p.N) && !(p.dbg & 3);
+            // Epilogue through a wave-private LDS patch living in the ring slot of the K-tile just consumed (free since
+            // barrier(v); protected from the next DMA by the barrier at the end): accumulators (D[n][m] layout = 4
+            // consecutive columns per lane) -> ds_write_b128 -> read back ROW-major, 8 columns per lane -> every global
+            // access of the fused epilogue (bias, row-bias, residuals, output) is a 16-byte piece of a contiguous row
+            // segment (WN*2 bytes), instead of 8-byte pieces of 32-byte segments straight from the MFMA layout
+            // (measured: 2.7 TB/s store rate, the dominant cost of the K=320 GEMMs).
+            constexpr int LDP = WN + 4;                            // patch row stride (floats)
+            float* patch = (float*)(smem + s_prev * STAGE) + wave * (16 * LDP);
+            const int m_w0 = tm * BM + wm * WM, n_w0 = tn * BN + wn * WN;
+            auto epilogue = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;   // FULL: no per-access guards -> exact store count
+                // an operand compiled in (EPI) but absent at run time reads the zero page with stride 0
+                const f16* bp = p.bias ? p.bias : p.zero_page;
                 const f16* rbp = p.rowbias ? p.rowbias : p.zero_page;
                 const f16* r1p = p.r1 ? p.r1 : p.zero_page;
                 const f16* r2p = p.r2 ? p.r2 : p.zero_page;
-                const f16* bp = p.bias ? p.bias : p.zero_page;
+                const int mbias = p.bias ? 1 : 0, mrb = p.rowbias ? 1 : 0, m1 = p.r1 ? 1 : 0, m2 = p.r2 ? 1 : 0;
                 const int ldrb = p.rowbias ? p.ld_rowbias : 0, ld1 = p.r1 ? p.ld_r1 : 0, ld2 = p.r2 ? p.ld_r2 : 0;
-                const int mrb = p.rowbias ? 1 : 0, m1 = p.r1 ? 1 : 0, m2 = p.r2 ? 1 : 0, mbias = p.bias ? 1 : 0;
-                const int N4 = p.N - 4;
-                size_t orow[FM];
-                size_t rrow1[FM], rrow2[FM], rrowb[FM];
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
-                    const int mc = min(mb + i * 16, p.M - 1);
-                    orow[i] = (size_t)mc * p.ld_out;
-                    rrow1[i] = (size_t)mc * ld1;
-                    rrow2[i] = (size_t)mc * ld2;
-                    rrowb[i] = (size_t)(mc / p.rows_per_group) * ldrb;
-                }
-                f16x4 rb[2][FM], q1[2][FM], q2[2][FM], bb[2];
-                auto fetch = [&](int j, int set) {
-                    const int n = nb + j * 16;
-                    const int nc = n < p.N ? n : N4;
-                    bb[set] = *(const f16x4*)(bp + nc * mbias);
 #pragma unroll
-                    for (int i = 0; i < FM; ++i) {
-                        rb[set][i] = *(const f16x4*)(rbp + rrowb[i] + nc * mrb);
-                        q1[set][i] = *(const f16x4*)(r1p + rrow1[i] + nc * m1);
-                        q2[set][i] = *(const f16x4*)(r2p + rrow2[i] + nc * m2);
-                    }
-                };
-                fetch(0, 0);
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const int set = j & 1;
-                    if (j + 1 < FN) fetch(j + 1, set ^ 1);
-                    const int n = nb + j * 16;
-                    const f32x4 bv = {(float)bb[set][0], (float)bb[set][1], (float)bb[set][2], (float)bb[set][3]};
-#pragma unroll
-                    for (int i = 0; i < FM; ++i) {
-                        const int m = mb + i * 16;
-                        f32x4 val = acc[i][j] + bv;
-                        val += (f32x4){(float)rb[set][i][0], (float)rb[set][i][1], (float)rb[set][i][2], (float)rb[set][i][3]};
-                        if (p.act == EW_ACT_SILU) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) val[e] = ew_silu(val[e]);
-                        }
-                        val *= p.c_acc;
-                        val += p.c_r1 * (f32x4){(float)q1[set][i][0], (float)q1[set][i][1], (float)q1[set][i][2], (float)q1[set][i][3]};
-                        val += p.c_r2 * (f32x4){(float)q2[set][i][0], (float)q2[set][i][1], (float)q2[set][i][2], (float)q2[set][i][3]};
-                        if (m < p.M && n < p.N)
-                            *(f16x4*)(p.out + orow[i] + n) = (f16x4){(f16)val[0], (f16)val[1], (f16)val[2], (f16)val[3]};
+                    for (int j = 0; j < FN; ++j) {
+                        *(f32x4*)(patch + frow * LDP + j * 16 + fks * 4) = acc[i][j];
                         acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     }
-                }
-            } else {
-                if constexpr (FN % 2 == 0) {
+                    __builtin_amdgcn_wave_barrier();
+                    if constexpr ((EPI & 8) == 0) {
+                        constexpr bool RB = EPI & 1, R1 = EPI & 2, R2 = EPI & 4;
+                        constexpr int VPR = WN / 8;                 // 16-byte output vectors per row
+                        constexpr int ITERS = (16 * VPR + 63) / 64;
 #pragma unroll
-                    for (int q = 0; q < FN / 2; ++q) {
-                        const int ns = nb + q * 32;                      // staged column of the value fragment
-                        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
-                        if (p.bias && ns < p.N) {
-                            const f16x4 b0 = *(const f16x4*)(p.bias + ns);
-                            const f16x4 b1 = *(const f16x4*)(p.bias + ns + 16);
-                            bv = (f32x4){(float)b0[0], (float)b0[1], (float)b0[2], (float)b0[3]};
-                            bg = (f32x4){(float)b1[0], (float)b1[1], (float)b1[2], (float)b1[3]};
-                        }
-                        const int no = ((tn * BN + wn * WN) >> 1) + q * 16 + fks * 4;
+                        for (int it = 0; it < ITERS; ++it) {
+                            const int idx = it * 64 + lane;
+                            const bool live = (16 * VPR) % 64 == 0 || idx < 16 * VPR;
+                            const int row = live ? idx / VPR : 0, c8 = live ? (idx - row * VPR) * 8 : 0;
+                            const int m = m_w0 + i * 16 + row, n = n_w0 + c8;
+                            const int mc = FULL ? m : min(m, p.M - 1), nc = (FULL || n + 8 <= p.N) ? n : 0;
+                            const f32x4 lo = *(const f32x4*)(patch + row * LDP + c8);
+                            const f32x4 hi = *(const f32x4*)(patch + row * LDP + c8 + 4);
+                            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            const f16x8 bv = *(const f16x8*)(bp + nc * mbias);
+                            f16x8 rbv, q1v, q2v;
+                            if constexpr (RB) rbv = *(const f16x8*)(rbp + (size_t)(mc / p.rows_per_group) * ldrb + nc * mrb);
+                            if constexpr (R1) q1v = *(const f16x8*)(r1p + (size_t)mc * ld1 + nc * m1);
+                            if constexpr (R2) q2v = *(const f16x8*)(r2p + (size_t)mc * ld2 + nc * m2);
+                            f16x8 o;
 #pragma unroll
-                        for (int i = 0; i < FM; ++i) {
-                            const int m = mb + i * 16;
-                            if (m < p.M && ns < p.N) {
-                                const f32x4 vv = acc[i][2 * q] + bv, gg = acc[i][2 * q + 1] + bg;
-                                f16x4 o;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) o[e] = (f16)(vv[e] * ew_gelu(gg[e]));
-                                *(f16x4*)(p.out + (size_t)m * p.ld_out + no) = o;
+                            for (int e = 0; e < 8; ++e) {
+                                float x = v[e] + (float)bv[e];
+                                if constexpr (RB) x += (float)rbv[e];
+                                if (p.act == EW_ACT_SILU) x = ew_silu(x);
+                                x *= p.c_acc;
+                                if constexpr (R1) x += p.c_r1 * (float)q1v[e];
+                                if constexpr (R2) x += p.c_r2 * (float)q2v[e];
+                                o[e] = (f16)x;
                             }
-                            acc[i][2 * q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            acc[i][2 * q + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            if (FULL ? live : (live && m < p.M && n + 8 <= p.N && !(p.dbg & 1)))
+                                *(f16x8*)(p.out + (size_t)m * p.ld_out + n) = o;
+                            else if (!FULL && live && m < p.M && !(p.dbg & 1)) {
+                                for (int e = 0; e < 8; ++e)                     // ragged N edge (e.g. conv_out N=4)
+                                    if (n + e < p.N) p.out[(size_t)m * p.ld_out + n + e] = o[e];
+                            }
+                        }
+                    } else {
+                        // GEGLU: staged columns come in blocks of 32 = [16 value | 16 gate]; output has WN/2 columns
+                        constexpr int VPR = WN / 16;                // 16-byte output vectors per row
+                        constexpr int ITERS = (16 * VPR + 63) / 64;
+#pragma unroll
+                        for (int it = 0; it < ITERS; ++it) {
+                            const int idx = it * 64 + lane;
+                            const bool live = (16 * VPR) % 64 == 0 || idx < 16 * VPR;
+                            const int row = live ? idx / VPR : 0, ov = live ? idx - row * VPR : 0;
+                            const int q = ov >> 1, c = (ov & 1) * 8;                 // 32-column block q, 8 columns at c
+                            const int m = m_w0 + i * 16 + row;
+                            const int ns = n_w0 + q * 32 + c;                       // staged column of the value
+                            const int nsc = (FULL || ns < p.N) ? ns : 0;          // out-of-range columns only ever feed discarded lanes
+                            const float* pr = patch + row * LDP + q * 32 + c;
+                            const f32x4 v0 = *(const f32x4*)(pr), v1 = *(const f32x4*)(pr + 4);
+                            const f32x4 g0 = *(const f32x4*)(pr + 16), g1 = *(const f32x4*)(pr + 20);
+                            const f16x8 bvv = *(const f16x8*)(bp + nsc * mbias), bgg = *(const f16x8*)(bp + (nsc + 16) * mbias);
+                            const float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                            const float gg[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                            f16x8 o;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = (f16)((vv[e] + (float)bvv[e]) * ew_gelu(gg[e] + (float)bgg[e]));
+                            const int no = (n_w0 >> 1) + q * 16 + c;
+                            if (FULL ? live : (live && m < p.M && ns < p.N && !(p.dbg & 1)))
+                                *(f16x8*)(p.out + (size_t)m * p.ld_out + no) = o;
                         }
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
+            };
+            if (p.dbg & 2) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) { asm volatile("" :: "v"(acc[i][j])); acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            } else {
+                if (stores_behind) epilogue(std::true_type{}); else epilogue(std::false_type{});
+                // the patch lives in the ring slot the NEXT DMA (stage at the top of the next position) will overwrite
+                EW_WAIT_LGKM0();
+                EW_COMPILER_FENCE();
+                __builtin_amdgcn_s_barrier();
+                EW_COMPILER_FENCE();
             }
+            if (staged < V) { stage(smem + s_prev * STAGE); ++staged; }   // the DMA deferred at this tile's last barrier
         }
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MODE>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, int EPI>
 ew_status launch2(const GemmP& p, hipStream_t s) {
+    constexpr int NW = WAVES_M * WAVES_N;
     GemmP q = p;
     q.tiles_m = ew_cdiv(p.M, BM);
     q.tiles_n = ew_cdiv(p.N, BN);
-    const size_t lds = 3 * (BM + BN) * 128;
+    const size_t lds = NSTAGE * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WAVES_M, WAVES_N, MODE>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE, MODE, EPI>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { ew_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return EW_ERR_HIP; }
         attr_set = true;
     }
     const long long tiles = (long long)q.tiles_m * q.tiles_n;
     if (tiles <= 0 || tiles > 0x7fffffffLL) { ew_set_error("ew_gemm_f16: bad grid"); return EW_ERR_INVALID_ARG; }
-    int grid = 256;                                   // one persistent workgroup per CU (MI355X: 256 CUs)
+    int grid = NW == 8 ? 256 : 512;                   // persistent: 1 x 8-wave or 2 x 4-wave workgroups per CU (256 CUs)
     if (tiles < grid) grid = (int)((tiles + 7) / 8 * 8);
-    hipLaunchKernelGGL((gemm2_kernel<BM, BN, WAVES_M, WAVES_N, MODE>), dim3(grid), dim3(512), lds, s, q);
+    hipLaunchKernelGGL((gemm2_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE, MODE, EPI>), dim3(grid), dim3(64 * NW), lds, s, q);
     return ew_check_launch("ew_gemm_f16(gen2)");
 }
 
+// Tile / workgroup shape.  variant 0 (default): 8-wave workgroups, 3-stage ring (256x160 | 128x256);
+// variant 1: 4-wave workgroups, 2 per CU, 2-stage ring (128x160 | 128x128) -- one group's epilogue (memory phase)
+// overlaps the other group's MFMA phase.  Selected by ew_set_gemm_debug bit 4 for A/B measurements.
+template <int MODE, int EPI>
+ew_status dispatch_tile(const GemmP& p, hipStream_t s) {
+    const bool v1 = (p.dbg & 16) != 0;
+    if constexpr (EPI & 8) {
+        if (v1) return launch2<128, 128, 2, 2, 2, MODE, EPI>(p, s);
+        return launch2<128, 256, 2, 4, 3, MODE, EPI>(p, s);
+    } else {
+        if (p.N % 160 == 0) {
+            if (v1) return launch2<128, 160, 2, 2, 2, MODE, EPI>(p, s);
+            return launch2<256, 160, 4, 2, 3, MODE, EPI>(p, s);
+        }
+        if (v1) return launch2<128, 128, 2, 2, 2, MODE, EPI>(p, s);
+        return launch2<128, 256, 2, 4, 3, MODE, EPI>(p, s);
+    }
+}
+
+// operand sets that occur in the U-Net (evoworld_amd/unet.py); any other mask runs on the smallest compiled superset
 template <int MODE>
-ew_status dispatch_mode(const GemmP& p, hipStream_t s) {
-    if (p.act != EW_ACT_GEGLU && p.N % 160 == 0) return launch2<256, 160, 4, 2, MODE>(p, s);
-    return launch2<128, 256, 2, 4, MODE>(p, s);
+ew_status dispatch_epi(const GemmP& p, hipStream_t s) {
+    if (p.act == EW_ACT_GEGLU) {
+        if constexpr (MODE == EW_A_DENSE) return dispatch_tile<MODE, 8>(p, s);
+        else { ew_set_error("ew_gemm_f16: GEGLU epilogue is only built for dense mode"); return EW_ERR_UNSUPPORTED; }
+    }
+    const int mask = (p.rowbias ? 1 : 0) | (p.r1 ? 2 : 0) | (p.r2 ? 4 : 0);
+    if (mask == 0) return dispatch_tile<MODE, 0>(p, s);
+    if (mask == 1) return dispatch_tile<MODE, 1>(p, s);
+    if (mask == 2) return dispatch_tile<MODE, 2>(p, s);
+    if constexpr (MODE == EW_A_DENSE) {
+        if (mask == 3) return dispatch_tile<MODE, 3>(p, s);
+        if (mask == 6 || mask == 4) return dispatch_tile<MODE, 6>(p, s);
+    }
+    return dispatch_tile<MODE, 7>(p, s);
 }
 
 }  // namespace
 
 ew_status ew_gemm2_dispatch(const GemmP& p, hipStream_t s) {
-    if (p.mode == EW_A_CONV3X3) return dispatch_mode<EW_A_CONV3X3>(p, s);
-    if (p.mode == EW_A_CONVT3) return dispatch_mode<EW_A_CONVT3>(p, s);
-    return dispatch_mode<EW_A_DENSE>(p, s);
+    if (p.mode == EW_A_CONV3X3) return dispatch_epi<EW_A_CONV3X3>(p, s);
+    if (p.mode == EW_A_CONVT3) return dispatch_epi<EW_A_CONVT3>(p, s);
+    return dispatch_epi<EW_A_DENSE>(p, s);
 }

@@ -19,6 +19,7 @@ struct GemmP {
     int rows_per_group, act;
     float c_acc, c_r1, c_r2;
     int tiles_m, tiles_n;
+    int dbg;   // experiment switches (tools/bench_kernels.py): bit0 skip output stores, bit1 skip epilogue entirely
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;

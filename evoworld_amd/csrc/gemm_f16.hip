@@ -265,6 +265,8 @@ ew_status launch(const GemmP& p, hipStream_t s) {
 
 ew_status ew_gemm2_dispatch(const GemmP& p, hipStream_t s);   // gemm2_f16.hip
 static int g_gemm_gen = -1;
+static int g_gemm_dbg = 0;
+extern "C" void ew_set_gemm_debug(int d) { g_gemm_dbg = d; }
 extern "C" void ew_set_gemm_generation(int gen) { g_gemm_gen = gen; }
 extern "C" int ew_get_gemm_generation(void) {
     if (g_gemm_gen < 0) {
@@ -315,6 +317,7 @@ extern "C" ew_status ew_gemm_f16(const ew_gemm_args* a, void* stream) {
     p.stride = a->stride; p.upsample = a->upsample; p.tB = a->tB; p.tT = a->tT; p.tP = a->tP;
     p.rows_per_group = a->rows_per_group; p.act = a->act; p.c_acc = a->c_acc; p.c_r1 = a->c_r1; p.c_r2 = a->c_r2;
     p.tiles_m = p.tiles_n = 0;
+    p.dbg = g_gemm_dbg;
     hipStream_t s = (hipStream_t)stream;
     if (ew_get_gemm_generation() == 2) return ew_gemm2_dispatch(p, s);
     // generation 1 tile choice: every channel count of the U-Net is a multiple of 160 (320*k); GEGLU and odd sizes use 128

@@ -82,6 +82,7 @@ ew_status ew_gemm_f16(const ew_gemm_args* args, void* stream);
  * EW_GEMM_GEN overrides).  Same arguments, same results to rounding; kept selectable for A/B measurements. */
 void ew_set_gemm_generation(int gen);
 int ew_get_gemm_generation(void);
+void ew_set_gemm_debug(int flags);   /* measurement-only switches (bit0: skip stores, bit1: skip epilogue); 0 = normal */
 
 /* GroupNorm statistics + apply, channels-last fp16, over a (virtual) channel concat.
  * The normalised tensor has C_tot channels in `groups` groups; this call handles the C_src channels
