@@ -20,12 +20,13 @@
 namespace {
 
 __device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
+typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                                const f16* __restrict__ vt, f16* __restrict__ o, int S,
                                                                int heads, int ld_qk, long long ld_vt, int ld_o, float sl2,
                                                                int n_qtiles) {
-    __shared__ __attribute__((aligned(16))) char smem[16384];  // K tile [64 keys][64 d] | V^T tile [64 d][64 keys]
+    __shared__ __attribute__((aligned(16))) char smem[32768];  // 2 x { K tile [64 keys][64 d] | V^T tile [64 d][64 keys] }
     char* const kl = smem;
     char* const vl = smem + 8192;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,7 +71,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         vr0 = c < S ? *(const f16x8*)(vbase + key0) : z;
         vr1 = c + 8 < S ? *(const f16x8*)(vbase + key0 + 8) : z;
     };
-    auto write_tile = [&]() {
+    auto write_tile = [&](int buf) {
+        char* const kl = smem + buf * 16384;
+        char* const vl = kl + 8192;
         *(f16x8*)(kl + k_w0) = kr0;
         *(f16x8*)(kl + k_w1) = kr1;
         // 16-key group -> slot A = keys {0..3, 8..11}, slot B = keys {4..7, 12..15}
@@ -85,16 +88,24 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
-    // fragment read offsets
-    const int fr_sw = swz(lq);  // rows lq and lq+32 have the same swizzle: ((r+32)^((r+32)>>3))&7 == (r^(r>>3)^4)&7 -> differs
-    const int fr_sw1 = swz(lq + 32);
+    // fragment byte offsets inside a tile, shared by the K tile (row = key) and the V^T tile (row = d): row-block b (0/1),
+    // 16-byte slot pair s -> (b*32+lq)*128 + (((2s+lh) ^ swz(row)) << 4).  Precomputed: the loop was VALU-bound
+    // (rocprofv3: 23 VALU instructions per MFMA, VALU busy ~90 %), address arithmetic included.
+    int foff[2][4];
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) foff[bq][sq] = (bq * 32 + lq) * 128 + (((2 * sq + lh) ^ swz(bq * 32 + lq)) << 4);
 
+    constexpr float DEFER_THR = 6.0f;   // log2 units: the running max is raised only when a tile exceeds it by 2^6 (T13)
     const int nt = (S + 63) / 64;
     load_tile(0);
-    write_tile();
+    write_tile(0);
     __syncthreads();
     for (int j = 0; j < nt; ++j) {
         const int key0 = j * 64;
+        const char* kb = kl;                         // the buffer toggle lives in foff (bit 14), see the end of the loop
+        const char* vb = vl;
         if (j + 1 < nt) load_tile(key0 + 64);
 
         // ---- S^T = K Q^T : two 32-key blocks ----
@@ -103,11 +114,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) sacc[blk][i] = 0.f;
-            const int row = blk * 32 + lq;
-            const int sw = blk ? fr_sw1 : fr_sw;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const f16x8 kf = *(const f16x8*)(kl + row * 128 + (((2 * s + lh) ^ sw) << 4));
+                const f16x8 kf = *(const f16x8*)(kb + foff[blk][s]);
                 sacc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[blk], 0, 0, 0);
             }
         }
@@ -122,41 +131,62 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
                 }
         }
         // ---- online softmax (this lane: one query, 32 of the 64 keys; partner lane^32 has the rest) ----
-        float tmax = sacc[0][0];
+        float tmax = fmaxf(sacc[0][0], sacc[0][1]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sacc[0][r]);
+        for (int r = 2; r < 16; r += 2) tmax = fmaxf(fmaxf(tmax, sacc[0][r]), sacc[0][r + 1]);      // v_max3_f32 chain
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[1][r]);
+        for (int r = 0; r < 16; r += 2) tmax = fmaxf(fmaxf(tmax, sacc[1][r]), sacc[1][r + 1]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax * sl2);
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
+        const float mt = tmax * sl2;
+        // deferred max: raise the running max only when this tile exceeds it by > 2^DEFER_THR (P stays <= 2^6, exact in
+        // fp16's relative precision); the O / l rescale (34 VALU per lane) is skipped on almost every tile.
+        const bool raise = mt > m_run + DEFER_THR;
+        if (__any(raise)) {
+            const float m_new = raise ? mt : m_run;
+            const float alpha = exp2f(m_run - m_new);       // 1 for the lanes that keep their max; 0 on the first tile
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+        }
+        // P = exp2(S*c - m) -> fp16 pairs (round-toward-zero pack: one instruction per pair; its bias cancels because the
+        // normaliser l below is accumulated from the SAME rounded values, with v_dot2)
         f16x8 pf[4];
+        const float nm = -m_run;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(sacc[blk][r] * sl2 - m_new);
-                psum += pv;
-                pf[blk * 2 + (r >> 3)][r & 7] = (f16)pv;
-            }
-        l_run = l_run * alpha + psum;
+            for (int g2 = 0; g2 < 2; ++g2) {
+                unsigned w[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+                for (int e = 0; e < 4; ++e) {
+                    const int r = g2 * 8 + e * 2;
+                    const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[blk][r], sl2, nm));
+                    const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[blk][r + 1], sl2, nm));
+                    const h2_t ph = __builtin_amdgcn_cvt_pkrtz(p0, p1);
+                    const h2_t one = {(__fp16)1.0f, (__fp16)1.0f};
+                    l_run = __builtin_amdgcn_fdot2(ph, one, l_run, false);
+                    w[e] = __builtin_bit_cast(unsigned, ph);
+                }
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 wv = {w[0], w[1], w[2], w[3]};
+                pf[blk * 2 + g2] = __builtin_bit_cast(f16x8, wv);
+            }
         // ---- O^T += V^T P^T ----
 #pragma unroll
         for (int g = 0; g < 4; ++g) {       // 16-key group (MFMA k-step)
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const int row = db * 32 + lq;
-                const int sw = db ? fr_sw1 : fr_sw;
-                const f16x8 vf = *(const f16x8*)(vl + row * 128 + (((2 * g + lh) ^ sw) << 4));
+                const f16x8 vf = *(const f16x8*)(vb + foff[db][g]);
                 oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[g], oacc[db], 0, 0, 0);
             }
         }
-        __syncthreads();
-        if (j + 1 < nt) write_tile();
+        // double-buffered tiles: the other buffer was last read in iteration j-1 (every wave passed that barrier)
+        if (j + 1 < nt) write_tile((j + 1) & 1);
+#pragma unroll
+        for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+            for (int sq = 0; sq < 4; ++sq) foff[bq][sq] ^= 16384;   // next tile sits in the other buffer
         __syncthreads();
     }
     // ---- normalise + store: lane holds query q_idx, d = 32*db + 8*(r>>2) + 4*lh + (r&3) ----
@@ -178,8 +208,6 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 // ---------------------------------------------------------------------------------------------
 // temporal attention: half-wave (32 lanes) per (batch, pixel, head) problem, lane = frame t
 // ---------------------------------------------------------------------------------------------
-typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
-
 __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                             const f16* __restrict__ v, f16* __restrict__ o, int B, int T,
                                                             int S, int heads, int ld, int ld_o, float scale,

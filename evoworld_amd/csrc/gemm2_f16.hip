@@ -210,6 +210,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // D[n][m]
     };
 
+    if (p.dbg & 64) {
+        // Chip-wide phase staggering: persistent workgroups that start together stay in lock-step over the WHOLE chip (same
+        // tile shape, same duration), so HBM sees all 256 store-bound epilogues at once and idles during the MFMA phases.
+        // Spreading the start over one tile period makes the write traffic continuous.
+        const int period = nk * 20 + 48;                                  // in s_sleep(1) units of 64 cycles
+        const int mine = (int)(((blockIdx.x * 97u) & 255u) * (unsigned)period) >> 8;
+        for (int i = 0; i < mine; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     if constexpr (NW == 4) {
         // Two 4-wave workgroups share a CU.  Started together they stay in lock-step (same tile shape, same duration) and hit
         // their store-bound epilogues at the same time; delaying the second half of the grid by ~half a tile makes one

@@ -6,7 +6,7 @@ from evoworld_amd import _lib
 import tools.bench_kernels as B
 lib = _lib.load()
 for rnd in range(1):
-    for dbg in (0, 16, 48):
+    for dbg in (0, 64):
         lib.ew_set_gemm_debug(dbg); print("variant dbg", dbg, "round", rnd)
         B.gemm_case("L0 qkv", 460800, 960, 320)
         B.gemm_case("L0 qk", 460800, 640, 320)
