@@ -19,7 +19,8 @@ SYMBOLS = [
     "ew_abi_version", "ew_last_error", "ew_gemm_f16", "ew_set_gemm_generation", "ew_get_gemm_generation", "ew_set_gemm_debug", "ew_groupnorm_stats_f16", "ew_groupnorm_apply_f16",
     "ew_layernorm_f16", "ew_attn_spatial_f16", "ew_attn_temporal_f16", "ew_nchw_f32_to_nhwc_f16",
     "ew_nhwc_f16_to_nchw_f32", "ew_euler_cfg_step", "ew_plucker_embed", "ew_cube2equi_gather",
-    "ew_depth_unproject", "ew_splat_cubemap", "ew_splat_resolve", "ew_equi2pers",
+    "ew_depth_unproject", "ew_splat_cubemap", "ew_splat_resolve", "ew_equi2pers", "ew_resize_aa_u8",
+    "ew_u8_hwc_to_f32_chw",
 ]
 
 
@@ -77,6 +78,8 @@ def load():
         "ew_splat_cubemap": [P, c_size_t, P, P, I, I, F, F, F, F, F, P],
         "ew_splat_resolve": [P, P, P, I, I, P],
         "ew_equi2pers": [P, P, P, I, I, I, I, I, F, P],
+        "ew_resize_aa_u8": [P, P, P, P, P, I, P, P, I, I, I, I, I, I, P],
+        "ew_u8_hwc_to_f32_chw": [P, P, I, I, I, P],
     }
     lib.ew_set_gemm_generation.argtypes = [c_int]
     lib.ew_set_gemm_generation.restype = None

@@ -156,6 +156,48 @@ __global__ void equi2pers_kernel(const uint8_t* __restrict__ equi, const float* 
     }
 }
 
+// Pillow-exact antialiased resampling pass for 8-bit images (ImagingResampleHorizontal/Vertical_8bpc): fixed-point
+// coefficients (22 fractional bits), out = clip8((2^21 + sum_k px[k]*kk[k]) >> 22).  One pass along `axis_stride`.
+// src/dst: [V, n_lines, ...] u8 with 3 channels; pass over the resampled axis of length n_in -> n_out.
+__global__ void resample_pass_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const int* __restrict__ kk,
+                                     const int* __restrict__ bounds, int ksize, long long n_img, int n_lines, int n_in,
+                                     int n_out, long long src_line_stride, long long src_elem_stride,
+                                     long long dst_line_stride, long long dst_elem_stride, long long src_img_stride,
+                                     long long dst_img_stride) {
+    const long long total = n_img * n_lines * n_out;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % n_out);
+        const long long t = i / n_out;
+        const int line = (int)(t % n_lines);
+        const long long img = t / n_lines;
+        const int xmin = bounds[xo * 2], xcnt = bounds[xo * 2 + 1];
+        const int* k = kk + (long long)xo * ksize;
+        const uint8_t* sp = src + img * src_img_stride + line * src_line_stride + xmin * src_elem_stride;
+        int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+        for (int x = 0; x < xcnt; ++x) {
+            const int c = k[x];
+            s0 += sp[0] * c; s1 += sp[1] * c; s2 += sp[2] * c;
+            sp += src_elem_stride;
+        }
+        uint8_t* dp = dst + img * dst_img_stride + line * dst_line_stride + xo * dst_elem_stride;
+        s0 >>= 22; s1 >>= 22; s2 >>= 22;
+        dp[0] = (uint8_t)(s0 < 0 ? 0 : (s0 > 255 ? 255 : s0));
+        dp[1] = (uint8_t)(s1 < 0 ? 0 : (s1 > 255 ? 255 : s1));
+        dp[2] = (uint8_t)(s2 < 0 ? 0 : (s2 > 255 ? 255 : s2));
+    }
+}
+
+// u8 HWC -> fp32 CHW in [-1,1]: (x / 255) * 2 - 1   (torchvision ToTensor + CustomRescale)
+__global__ void u8_hwc_to_f32_chw_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, long long n_img, int HW) {
+    const long long total = n_img * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long img = i / HW;
+        const int p = (int)(i - img * HW);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dst[(img * 3 + c) * HW + p] = ((float)src[i * 3 + c] / 255.0f) * 2.0f - 1.0f;
+    }
+}
+
 }  // namespace
 
 extern "C" ew_status ew_plucker_embed(const float* rays, const float* c2w, float* out, int N, int H, int W, void* stream) {
@@ -208,4 +250,28 @@ extern "C" ew_status ew_equi2pers(const uint8_t* equi, const float* rot, uint8_t
     hipLaunchKernelGGL(equi2pers_kernel, dim3(grid_for((long long)F * Hp * Wp)), dim3(256), 0, (hipStream_t)stream, equi,
                        rot, out, F, He, We, Hp, Wp, focal);
     return ew_check_launch("ew_equi2pers");
+}
+
+extern "C" ew_status ew_resize_aa_u8(const uint8_t* src, uint8_t* tmp, uint8_t* dst, const int* kk_h, const int* bounds_h,
+                                     int ksize_h, const int* kk_v, const int* bounds_v, int ksize_v, int V, int Hi, int Wi,
+                                     int Ho, int Wo, void* stream) {
+    EW_REQUIRE(src && tmp && dst && kk_h && bounds_h && kk_v && bounds_v, "ew_resize_aa_u8: null pointer");
+    EW_REQUIRE(V > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && ksize_h > 0 && ksize_v > 0, "ew_resize_aa_u8: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    // horizontal pass: [V,Hi,Wi,3] -> tmp [V,Hi,Wo,3]
+    hipLaunchKernelGGL(resample_pass_kernel, dim3(grid_for((long long)V * Hi * Wo)), dim3(256), 0, s, src, tmp, kk_h, bounds_h,
+                       ksize_h, (long long)V, Hi, Wi, Wo, (long long)Wi * 3, 3LL, (long long)Wo * 3, 3LL, (long long)Hi * Wi * 3,
+                       (long long)Hi * Wo * 3);
+    // vertical pass: lines = columns of tmp: [V,Hi,Wo,3] -> dst [V,Ho,Wo,3]
+    hipLaunchKernelGGL(resample_pass_kernel, dim3(grid_for((long long)V * Wo * Ho)), dim3(256), 0, s, tmp, dst, kk_v, bounds_v,
+                       ksize_v, (long long)V, Wo, Hi, Ho, 3LL, (long long)Wo * 3, 3LL, (long long)Wo * 3, (long long)Hi * Wo * 3,
+                       (long long)Ho * Wo * 3);
+    return ew_check_launch("ew_resize_aa_u8");
+}
+
+extern "C" ew_status ew_u8_hwc_to_f32_chw(const uint8_t* src, float* dst, int V, int H, int W, void* stream) {
+    EW_REQUIRE(src && dst && V > 0 && H > 0 && W > 0, "ew_u8_hwc_to_f32_chw: bad args");
+    hipLaunchKernelGGL(u8_hwc_to_f32_chw_kernel, dim3(grid_for((long long)V * H * W)), dim3(256), 0, (hipStream_t)stream, src,
+                       dst, (long long)V, H * W);
+    return ew_check_launch("ew_u8_hwc_to_f32_chw");
 }

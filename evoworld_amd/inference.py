@@ -1,0 +1,177 @@
+"""Inference drivers of the hot path -- the build's counterparts of the reference callers:
+
+  prepare_batch_data / process_batch     <- evoworld/inference/forward_evoworld.py:119-211          (C1, single clip)
+  Navigator.move_forward / navigate_curve_path / split_curve_into_segments / extend_segment
+                                         <- evoworld/inference/navigator_evoworld.py:146-154,173-231,303-318,394-448  (C2)
+  UnifiedLoopConsistencyPipeline.process_episode / convert_pano_to_pers
+                                         <- unified_loop_consistency.py:299-334,398-492               (C3, N-segment loop)
+
+Same tensor preparation and pipeline kwargs (decode_chunk_size=8, motion_bucket_id=127, fps=7, noise_aug_strength=0.02,
+mask_mem, per-window generator re-seeded with torch.manual_seed(-1)).  Differences, all device-side: frames stay tensors
+(no PIL / PNG / numpy round-trips between the stages, SURVEY.md §3.2 'a native design keeps all of this on-device'); the
+depth network (VGGT-1B, out of scope) is a duck-typed callable `depth_model(perspective_frames_u8) -> predictions dict`.
+File output (PNG dumps) is optional and off the hot path.
+"""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import reprojection as RP
+from .geometry import UNITY_TO_OPENCV, xyz_euler_to_four_by_four_matrix_batch, xyz_euler_to_three_by_four_matrix_batch
+from .plucker import equirectangular_to_ray, ray_c2w_to_plucker
+
+
+# ------------------------------------------------------------------ C1: single clip
+def prepare_batch_data(batch, args, rays, weight_dtype=torch.float32):
+    """batch: pixel_values [B,T,3,H,W] in [-1,1], cam_traj [B,T,6] (RDF, pos-scaled), memorized_pixel_values [B,T,3,H,W]
+    -> (first_frame, camera_traj [B,T,3,4], plucker_embedding [B,T,6,H/8,W/8], memorized_pixel_values, images)."""
+    images = batch["pixel_values"]
+    first_frame = images[:, 0].cuda()
+    raw = batch["cam_traj"].cuda()
+    B = raw.shape[0]
+    camera_traj = torch.zeros(B, args.num_frames, 3, 4, dtype=weight_dtype, device="cuda")
+    plucker = torch.zeros(B, args.num_frames, 6, args.height // 8, args.width // 8, dtype=weight_dtype, device="cuda")
+    for i in range(B):
+        camera_traj[i] = xyz_euler_to_three_by_four_matrix_batch(raw[i], relative=True)
+        plucker[i] = ray_c2w_to_plucker(rays, camera_traj[i])
+    return first_frame, camera_traj, plucker, batch["memorized_pixel_values"].cuda(), images
+
+
+def process_batch(batch, args, pipeline, rays, weight_dtype=torch.float32, output_path=None, episode="episode", **pipe_kw):
+    """One clip through the pipeline with the reference's fixed kwargs; returns the pipeline's frames (and saves PNGs when
+    output_path is given and the frames are PIL images)."""
+    first_frame, _traj, plucker, memory, images = prepare_batch_data(batch, args, rays, weight_dtype)
+    frames = pipeline(first_frame, height=args.height, width=args.width, num_frames=args.num_frames, decode_chunk_size=8,
+                      motion_bucket_id=127, fps=7, noise_aug_strength=0.02, plucker_embedding=plucker,
+                      memorized_pixel_values=memory, mask_mem=args.mask_mem, **pipe_kw).frames
+    if output_path and isinstance(frames, list):
+        d = os.path.join(output_path, episode, "predictions")
+        os.makedirs(d, exist_ok=True)
+        for i, f in enumerate(frames[0]):
+            f.save(os.path.join(d, f"{i + 1:03}.png"))
+    return frames
+
+
+# ------------------------------------------------------------------ C2: windowed navigation
+class Navigator:
+    def __init__(self, pipe, height=576, width=1024, num_frames=25, fps=7):
+        self.pipe, self.model_height, self.model_width, self.num_frames, self.fps = pipe, height, width, num_frames, fps
+        self.rays = torch.tensor(equirectangular_to_ray(height // 8, width // 8)).float().cuda()
+        self.memorized_images = None
+        self.generations = []
+
+    split_curve_into_segments = staticmethod(RP.split_curve_into_segments)
+
+    @staticmethod
+    def extend_segment(segment, n):
+        """Pad a short window by repeating its last pose (navigator_evoworld.py:146-154)."""
+        seg = list(segment)
+        while len(seg) < n:
+            seg.append(seg[-1].clone() if isinstance(seg[-1], torch.Tensor) else seg[-1])
+        return seg
+
+    def move_forward(self, image, segment, num_model_frames=25, num_inference_steps=25, noise_aug_strength=0.02,
+                     use_memory=False, **pipe_kw):
+        """One 25-pose window (navigator_evoworld.py:173-231): relative c2w -> Plücker -> pipeline with a CPU generator
+        re-seeded per window (every segment starts from identical noise), mask_mem = not use_memory."""
+        n = len(segment)
+        if n < num_model_frames:
+            segment = self.extend_segment(segment, num_model_frames)
+        raw = segment if isinstance(segment, torch.Tensor) else torch.stack(list(segment), dim=0)
+        raw = raw.cuda().float()
+        c2w = xyz_euler_to_three_by_four_matrix_batch(raw, relative=True)
+        pl = ray_c2w_to_plucker(self.rays, c2w)
+        generator = torch.manual_seed(-1)                                   # navigator_evoworld.py:198
+        frames = self.pipe(image.unsqueeze(0), num_frames=self.num_frames, width=self.model_width, height=self.model_height,
+                           decode_chunk_size=8, generator=generator, motion_bucket_id=127, fps=self.fps,
+                           num_inference_steps=num_inference_steps, noise_aug_strength=noise_aug_strength,
+                           plucker_embedding=pl[:25].unsqueeze(0), memorized_pixel_values=self.memorized_images.clone(),
+                           mask_mem=not use_memory, **pipe_kw).frames
+        return frames, n
+
+    def navigate_curve_path(self, path, start_image, num_inference_steps=25, memorized_images=None, infer_segment=False,
+                            segment_id=None, **pipe_kw):
+        """Windows [0:25],[24:49],... ; with infer_segment only window `segment_id` is generated (navigator :394-448)."""
+        self.memorized_images = memorized_images.clone()
+        segments = self.split_curve_into_segments(path)
+        generations, current = [], 0
+        image = start_image
+        for segment in segments:
+            if segment_id is not None and current < segment_id and infer_segment:
+                current += 1
+                continue
+            frames, n = self.move_forward(image, segment, num_inference_steps=num_inference_steps,
+                                          use_memory=(segment_id != 0), **pipe_kw)
+            generations.append((frames, n))
+            current += 1
+            if infer_segment and current > segment_id:
+                break
+        self.generations = generations
+        return generations
+
+
+# ------------------------------------------------------------------ C3: N-segment loop with evolving 3D memory
+class UnifiedLoopConsistencyPipeline:
+    """process_episode of unified_loop_consistency.py:398-492 with every stage on the device.
+    `frames_from_latents(latents[1,T,4,h,w]) -> float [T,3,H,W] in [-1,1]` stands for the VAE decode (row N1);
+    `depth_model(persp_u8 [F,384,512,3]) -> dict(depth, depth_conf, images, extrinsic, intrinsic)` stands for VGGT (row N4)."""
+
+    def __init__(self, pipeline, depth_model, frames_from_latents, height=576, width=1024, num_frames=25, num_segments=3,
+                 num_inference_steps=25, pano_size=(1000, 2000), face_res=512):
+        self.nav = Navigator(pipeline, height, width, num_frames)
+        self.depth_model, self.frames_from_latents = depth_model, frames_from_latents
+        self.height, self.width, self.num_frames, self.num_segments = height, width, num_frames, num_segments
+        self.steps = num_inference_steps
+        self.equi2pers = RP.Equi2Pers(height=384, width=512, fov_x=90.0, mode="bilinear")      # :178-183
+        self.pano_size, self.renderer = pano_size, RP.CubemapRenderer(face_res=face_res)
+
+    def convert_pano_to_pers(self, frames, camera_params, segment_id):
+        """frames float [F,3,H,W] in [-1,1] (device) -> uint8 [F,384,512,3] + target yaws in degrees (:299-334)."""
+        yaws = RP.calculate_target_yaws(camera_params, frames.shape[0], segment_id)
+        u8 = ((frames / 2 + 0.5).clamp(0, 1) * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()   # tensor_to_pil semantics
+        pers = self.equi2pers.batch(u8, [{"pitch": 0, "roll": 0, "yaw": float(y)} for y in yaws])
+        return pers, yaws / np.pi * 180.0
+
+    def process_episode(self, start_image, camera_params, image_latents_fn, save_dir=None, **pipe_kw):
+        """start_image float [3,H,W] in [-1,1]; camera_params [P,6] numpy (RDF, pos-scaled).  `image_latents_fn(first_frame,
+        memory [T,3,H,W]) -> dict(image_latents=[1,1+T,4,h,w], image_embeddings=[1,1,X])` stands for VAE-encode + CLIP.
+        Returns all generated frames [N,3,H,W] (25 -> 49 -> 73 ...)."""
+        dev = start_image.device
+        cam_t = torch.tensor(camera_params, dtype=torch.float32, device=dev)
+        all_frames = None
+        memory = torch.zeros(self.num_frames, 3, self.height, self.width, device=dev)       # 'empty_with_traj' memory
+        for seg in range(self.num_segments):
+            start_idx, end_idx, _ = RP.calculate_segment_indices(seg)
+            first = start_image if seg == 0 else all_frames[-1]
+            cond = image_latents_fn(first, memory)
+            gens = self.nav.navigate_curve_path(cam_t, first, num_inference_steps=self.steps, memorized_images=memory[None],
+                                                infer_segment=True, segment_id=seg, output_type="latent", **cond, **pipe_kw)
+            latents, _n = gens[-1]
+            frames = self.frames_from_latents(latents)
+            if all_frames is not None:
+                frames = frames[1:]                                                     # drop the duplicated first frame (:427-429)
+            all_frames = frames if all_frames is None else torch.cat([all_frames, frames], dim=0)
+            if seg < self.num_segments - 1:
+                pers, target_yaws = self.convert_pano_to_pers(all_frames, camera_params, seg)
+                temp_cam = np.array(camera_params, dtype=np.float64).copy()
+                s = max(0, end_idx - len(target_yaws))
+                temp_cam[s:end_idx, 4] = target_yaws[: end_idx - s]                        # :456-459
+                preds = self.depth_model(pers)
+                poses = xyz_euler_to_four_by_four_matrix_batch(torch.tensor(temp_cam, dtype=torch.float32), relative=True)
+                outdir = os.path.join(save_dir or "", f"rendered_panorama_vggt_open3d_{seg}")
+                panos = RP.predictions_to_target_view(preds, poses.numpy(), conf_thres=50.0, prediction_mode="depth_unproject",
+                                                      num_target_view=24, outdir=outdir, cubemap_renderer=_Sized(self.renderer, self.pano_size),
+                                                      return_device_tensor=True, save_png=bool(save_dir))
+                mem24 = RP.memory_to_pixel_values(panos, self.height, self.width)           # [24,3,H,W]
+                memory = torch.cat([start_image[None], mem24], dim=0)                      # [episode frame 1] + 24 reprojected (:277-279)
+        return all_frames
+
+
+class _Sized:
+    def __init__(self, cr, pano_size):
+        self.cr, self.pano_size = cr, pano_size
+
+    def render_cubemaps_to_panoramas(self, v, c, target, n, outdir):
+        return self.cr.render_cubemaps_to_panoramas(v, c, target, n, outdir, width=self.pano_size[1], height=self.pano_size[0])

@@ -202,3 +202,25 @@ def equi2pers(equi, rot, Hp, Wp, fov_x):
     out = torch.empty(F_, Hp, Wp, 3, dtype=torch.uint8, device=equi.device)
     _lib.check(lib.ew_equi2pers(_ptr(equi), _ptr(rot), _ptr(out), F_, He, We, Hp, Wp, float(fov_x), _stream()), "ew_equi2pers")
     return out
+
+
+def resize_aa_u8(src, coeffs_h, coeffs_v, Ho, Wo):
+    """src uint8 [V,Hi,Wi,3]; coeffs_* = (kk int32 [n_out,ksize], bounds int32 [n_out,2]) device tensors -> uint8 [V,Ho,Wo,3]."""
+    lib = _lib.load()
+    _req(src, torch.uint8, "src")
+    V, Hi, Wi, _ = src.shape
+    tmp = torch.empty(V, Hi, Wo, 3, dtype=torch.uint8, device=src.device)
+    dst = torch.empty(V, Ho, Wo, 3, dtype=torch.uint8, device=src.device)
+    (kh, bh), (kv, bv) = coeffs_h, coeffs_v
+    _lib.check(lib.ew_resize_aa_u8(_ptr(src), _ptr(tmp), _ptr(dst), _ptr(kh), _ptr(bh), kh.shape[1], _ptr(kv), _ptr(bv),
+                                   kv.shape[1], V, Hi, Wi, Ho, Wo, _stream()), "ew_resize_aa_u8")
+    return dst
+
+
+def u8_hwc_to_f32_chw(src):
+    lib = _lib.load()
+    _req(src, torch.uint8, "src")
+    V, H, W, _ = src.shape
+    dst = torch.empty(V, 3, H, W, dtype=torch.float32, device=src.device)
+    _lib.check(lib.ew_u8_hwc_to_f32_chw(_ptr(src), _ptr(dst), V, H, W, _stream()), "ew_u8_hwc_to_f32_chw")
+    return dst

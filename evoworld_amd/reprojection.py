@@ -341,3 +341,49 @@ def split_curve_into_segments(path):
     if e - s > 1 and s < total:
         segs.append(path[s:])
     return segs
+
+
+# ------------------------------------------------------------------ R7: memory panoramas -> pipeline input (PIL-exact resize)
+_coeff_cache = {}
+
+
+def resample_coeffs(in_size, out_size):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR filter (support 1.0) over the full box:
+    returns (kk int32 [out, ksize], bounds int32 [out, 2] = (xmin, count)).  This is what
+    torchvision.transforms.Resize((576,1024)) does to the 1000x2000 PIL memory panoramas
+    (dataset/CameraTrajDataset.py:586-619, unified_loop_consistency.py:422); verified bit-exact against PIL itself."""
+    key = (in_size, out_size)
+    if key in _coeff_cache:
+        return _coeff_cache[key]
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = np.array([max(0.0, 1.0 - abs((x + xmin - center + 0.5) * ss)) for x in range(xmax)], dtype=np.float64)
+        ww = w.sum()
+        if ww != 0.0:
+            w = w / ww
+        q = w * (1 << 22)
+        kk[xx, :xmax] = np.where(q < 0, q - 0.5, q + 0.5).astype(np.int64)      # C cast: truncation toward zero
+        bounds[xx] = (xmin, xmax)
+    out = (torch.from_numpy(kk), torch.from_numpy(bounds))
+    _coeff_cache[key] = out
+    return out
+
+
+def memory_to_pixel_values(panos_u8, height=576, width=1024):
+    """uint8 [V,Hi,Wi,3] (device) -> fp32 [V,3,height,width] in [-1,1]: Resize (PIL bilinear, antialiased) -> ToTensor ->
+    x*2-1, without leaving the GPU (the reference goes numpy -> PIL -> torch per panorama, unified_loop_consistency.py:422)."""
+    V, Hi, Wi, _ = panos_u8.shape
+    dev = panos_u8.device
+    ch = tuple(t.to(dev) for t in resample_coeffs(Wi, width))
+    cv = tuple(t.to(dev) for t in resample_coeffs(Hi, height))
+    small = ops.resize_aa_u8(panos_u8.contiguous(), ch, cv, height, width) if (Hi, Wi) != (height, width) else panos_u8.contiguous()
+    return ops.u8_hwc_to_f32_chw(small)

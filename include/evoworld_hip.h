@@ -170,6 +170,15 @@ ew_status ew_splat_resolve(const unsigned long long* zbuf, const uint8_t* rgb, u
 ew_status ew_equi2pers(const uint8_t* equi, const float* rot, uint8_t* out, int F, int He, int We, int Hp, int Wp,
                        float fov_x_deg, void* stream);
 
+/* Pillow-exact antialiased bilinear resize of 8-bit RGB images (two fixed-point passes, horizontal then vertical, 8-bit
+ * intermediate), i.e. what torchvision.transforms.Resize does to the PIL memory panoramas before they enter the pipeline
+ * (dataset/CameraTrajDataset.py:586-619 via unified_loop_consistency.py:422).  Coefficient tables kk [n_out, ksize] (int32,
+ * 22 fractional bits) and bounds [n_out, 2] = (xmin, count) are built on the host (evoworld_amd.reprojection.resample_coeffs).
+ * src [V,Hi,Wi,3] -> tmp [V,Hi,Wo,3] -> dst [V,Ho,Wo,3].  ew_u8_hwc_to_f32_chw: (x/255)*2-1 -> fp32 [V,3,H,W]. */
+ew_status ew_resize_aa_u8(const uint8_t* src, uint8_t* tmp, uint8_t* dst, const int* kk_h, const int* bounds_h, int ksize_h,
+                          const int* kk_v, const int* bounds_v, int ksize_v, int V, int Hi, int Wi, int Ho, int Wo, void* stream);
+ew_status ew_u8_hwc_to_f32_chw(const uint8_t* src, float* dst, int V, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
