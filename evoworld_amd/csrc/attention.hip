@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         // P = exp2(S*c - m) -> fp16 pairs (round-toward-zero pack: one instruction per pair; its bias cancels because the
         // normaliser l below is accumulated from the SAME rounded values, with v_dot2)
         f16x8 pf[4];
-        const float nm = -m_run;
+        const f32x2 nm2 = {-m_run, -m_run}, sl22 = {sl2, sl2};
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -161,9 +161,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = g2 * 8 + e * 2;
-                    const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[blk][r], sl2, nm));
-                    const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[blk][r + 1], sl2, nm));
-                    const h2_t ph = __builtin_amdgcn_cvt_pkrtz(p0, p1);
+                    const f32x2 sv = {sacc[blk][r], sacc[blk][r + 1]};
+                    const f32x2 t = __builtin_elementwise_fma(sv, sl22, nm2);          // v_pk_fma_f32: two scores per VALU issue
+                    const h2_t ph = __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]));
                     const h2_t one = {(__fp16)1.0f, (__fp16)1.0f};
                     l_run = __builtin_amdgcn_fdot2(ph, one, l_run, false);
                     w[e] = __builtin_bit_cast(unsigned, ph);

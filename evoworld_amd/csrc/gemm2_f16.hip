@@ -82,12 +82,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
     const int srow = lane >> 3;
     const int slot = (lane & 7) ^ srow;
 
-    // ---------------- loader state (runs 2 K-tiles ahead of the MFMA stream, across output tiles) ----------------
-    int ld_i = 0, ld_kt = 0, ld_tap = 0, ld_cc = 0, ld_key = -1;
-    int a_y[GA], a_x[GA], a_img[GA], a_row[GA];
-    const f16* a_src[GA];
-    bool a_ok[GA];
+    // ---------------- loader state (runs NSTAGE K-tiles ahead of the MFMA stream, across output tiles) ----------------
+    // Per A row of this lane: element offset of the CENTRE tap in each source tensor (+ the lane's 16-byte slot), a tap
+    // validity mask, and for the nearest-x2-upsampled conv a 2-bit (dy, dx) code per tap.  A K-tile's source address is then
+    // centre + a wave-uniform tap delta: ~5 VALU per row per K-tile, no re-derivation of (img, y, x) inside the stream
+    // (an ablation showed the loader's address arithmetic, not DMA bandwidth, was costing ~30 % of the main loop).
+    int ld_i = 0, ld_kt = 0, ld_tap = 0, ld_cc = 0;
+    long long a_off1[GA], a_off2[GA];
+    int a_mask[GA];                        // bits 0..8 tap validity, bits 16..27 upsample (dy,dx) codes
     const f16* b_ptr[GB];
+    constexpr int NTAP = MODE == EW_A_CONV3X3 ? 9 : (MODE == EW_A_CONVT3 ? 3 : 1);
 
     auto loader_new_tile = [&]() {
         const int id = ld_i * G + seq0;
@@ -97,18 +101,43 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
         for (int i = 0; i < GA; ++i) {
             int m = m0 + (wave + NW * i) * 8 + srow;
             m = m < p.M ? m : p.M - 1;
-            a_row[i] = m;
+            long long ctr;
+            int mask = 1, dcode = 0;
             if constexpr (MODE == EW_A_CONV3X3) {
                 const int hw = p.h_out * p.w_out;
                 const int img = m / hw, rem = m - img * hw;
-                a_img[i] = img; a_y[i] = rem / p.w_out; a_x[i] = rem - a_y[i] * p.w_out;
+                const int oy = rem / p.w_out, ox = rem - oy * p.w_out;
+                const int hlim = p.upsample ? 2 * p.h_in : p.h_in, wlim = p.upsample ? 2 * p.w_in : p.w_in;
+                const int cy = oy * p.stride, cx = ox * p.stride;               // centre tap, in (possibly upsampled) input coords
+                mask = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
+                    if (iy >= 0 && iy < hlim && ix >= 0 && ix < wlim) mask |= 1 << t;
+                }
+                if (p.upsample) {
+                    const int sy = cy >> 1, sx = cx >> 1;                        // source pixel of the centre tap
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        dcode |= ((((cy + k - 1) >> 1) - sy) + 1) << (2 * k);        // dy(ky) in {-1,0,1} -> 2 bits
+                        dcode |= ((((cx + k - 1) >> 1) - sx) + 1) << (6 + 2 * k);    // dx(kx)
+                    }
+                    ctr = ((long long)img * p.h_in + sy) * p.w_in + sx;
+                } else {
+                    ctr = ((long long)img * p.h_in + cy) * p.w_in + cx;
+                }
             } else if constexpr (MODE == EW_A_CONVT3) {
                 const int tp = p.tT * p.tP;
-                const int b = m / tp, rem = m - b * tp;
-                a_img[i] = b; a_y[i] = rem / p.tP; a_x[i] = rem - a_y[i] * p.tP;
+                const int bb = m / tp, rem = m - bb * tp;
+                const int t = rem / p.tP, x = rem - t * p.tP;
+                mask = (t > 0 ? 1 : 0) | 2 | (t + 1 < p.tT ? 4 : 0);
+                ctr = ((long long)bb * p.tT + t) * p.tP + x;
             } else {
-                a_img[i] = 0; a_y[i] = 0; a_x[i] = 0;
+                ctr = m;
             }
+            a_mask[i] = mask | (dcode << 16);
+            a_off1[i] = ctr * p.lda + slot * 8;
+            a_off2[i] = ctr * p.lda2 + slot * 8;
         }
 #pragma unroll
         for (int j = 0; j < GB; ++j) {
@@ -116,49 +145,45 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
             n = n < p.N ? n : p.N - 1;
             b_ptr[j] = p.w + (size_t)n * p.K + slot * 8;
         }
-        ld_kt = 0; ld_tap = 0; ld_cc = 0; ld_key = -1;
+        ld_kt = 0; ld_tap = 0; ld_cc = 0;
     };
 
     auto stage = [&](char* buf) {   // issue the DMA of the next K-tile of the stream into ring slot `buf`
         if (ld_kt == 0) loader_new_tile();
         const int tap = ld_tap, cc = ld_cc;
         const bool second = cc >= p.c1;
-        const int key = tap * 2 + (second ? 1 : 0);
-        if (key != ld_key) {
-            ld_key = key;
-            const f16* base = second ? p.a2 : p.a;
-            const int ld = second ? p.lda2 : p.lda;
-#pragma unroll
-            for (int i = 0; i < GA; ++i) {
-                long long pix;
-                if constexpr (MODE == EW_A_CONV3X3) {
-                    const int ky = tap / 3, kx = tap - ky * 3;
-                    int iy = a_y[i] * p.stride + ky - 1, ix = a_x[i] * p.stride + kx - 1;
-                    const int hlim = p.upsample ? 2 * p.h_in : p.h_in, wlim = p.upsample ? 2 * p.w_in : p.w_in;
-                    const bool ok = iy >= 0 && iy < hlim && ix >= 0 && ix < wlim;
-                    if (p.upsample) { iy >>= 1; ix >>= 1; }
-                    pix = ok ? ((long long)a_img[i] * p.h_in + iy) * p.w_in + ix : -1;
-                } else if constexpr (MODE == EW_A_CONVT3) {
-                    const int t = a_y[i] + tap - 1;
-                    pix = (t >= 0 && t < p.tT) ? ((long long)a_img[i] * p.tT + t) * p.tP + a_x[i] : -1;
-                } else {
-                    pix = a_row[i];
-                }
-                a_ok[i] = pix >= 0;
-                a_src[i] = (pix >= 0 ? base + pix * ld : p.zero_page) + slot * 8;
-            }
-        }
+        const f16* base = second ? p.a2 : p.a;
+        const int ld = second ? p.lda2 : p.lda;
         const int ch = second ? cc - p.c1 : cc;
+        int dpix = 0;                                                       // wave-uniform tap delta in pixels
+        if constexpr (MODE == EW_A_CONV3X3) dpix = (tap / 3 - 1) * p.w_in + (tap % 3 - 1);
+        else if constexpr (MODE == EW_A_CONVT3) dpix = (tap - 1) * p.tP;
+        const long long dl = (long long)dpix * ld + ch;
+        const f16* zp = p.zero_page + slot * 8;
 #pragma unroll
-        for (int i = 0; i < GA; ++i) glds16(a_src[i] + (a_ok[i] ? ch : 0), buf + (wave + NW * i) * 1024);
+        for (int i = 0; i < GA; ++i) {
+            const long long off = second ? a_off2[i] : a_off1[i];
+            const f16* src = base + off + dl;
+            if constexpr (MODE == EW_A_CONV3X3) {
+                if (p.upsample) {                                           // per-row deltas (nearest-x2 source coordinates)
+                    const int dc = a_mask[i] >> 16;
+                    const int dy = ((dc >> (2 * (tap / 3))) & 3) - 1, dx = ((dc >> (6 + 2 * (tap % 3))) & 3) - 1;
+                    src = base + off + ((long long)(dy * p.w_in + dx) * ld + ch);
+                }
+            }
+            if constexpr (MODE != EW_A_DENSE) src = ((a_mask[i] >> tap) & 1) ? src : zp;
+            glds16(src, buf + (wave + NW * i) * 1024);
+        }
         const size_t koff = (size_t)ld_kt * BK;
 #pragma unroll
         for (int j = 0; j < GB_FULL; ++j) glds16(b_ptr[j] + koff, buf + A_BYTES + (wave + NW * j) * 1024);
         if constexpr (GB > GB_FULL) {
             if (has_tail) glds16(b_ptr[GB - 1] + koff, buf + A_BYTES + (wave + NW * (GB - 1)) * 1024);
         }
-        ld_cc += BK;
-        if (ld_cc == C) { ld_cc = 0; ++ld_tap; }
+        // K order is CHANNEL-CHUNK major, tap minor: the taps of one 64-channel chunk re-read (shifted) the same input
+        // lines, so the chunk's footprint (~66 KB per workgroup) is fetched from HBM/MALL once and re-hit in L2 for the
+        // other taps; tap-major order re-fetched the whole C-wide footprint (10 MB per XCD > 4 MB L2) for every tap.
+        if (++ld_tap == NTAP) { ld_tap = 0; ld_cc += BK; }
         if (++ld_kt == nk) { ld_kt = 0; ++ld_i; }
     };
 
@@ -298,79 +323,119 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
                 const f16* r2p = p.r2 ? p.r2 : p.zero_page;
                 const int mbias = p.bias ? 1 : 0, mrb = p.rowbias ? 1 : 0, m1 = p.r1 ? 1 : 0, m2 = p.r2 ? 1 : 0;
                 const int ldrb = p.rowbias ? p.ld_rowbias : 0, ld1 = p.r1 ? p.ld_r1 : 0, ld2 = p.r2 ? p.ld_r2 : 0;
+                // vmcnt is an IN-ORDER counter: a load issued after a store cannot be waited for without also draining that
+                // store.  So (a) bias vectors (column-only) are loaded once, before any store; (b) the row operands of step
+                // s+1 (row-bias, residuals) are requested BEFORE the store of step s.  With loads interleaved after each store
+                // the epilogue serialised into ~12 store round trips per tile (measured: epilogue = main loop at K=320).
+                if constexpr ((EPI & 8) == 0) {
+                    constexpr bool RB = EPI & 1, R1 = EPI & 2, R2 = EPI & 4;
+                    constexpr int VPR = WN / 8;                 // 16-byte output vectors per row
+                    constexpr int ITERS = (16 * VPR + 63) / 64;
+                    constexpr int NS = FM * ITERS;
+                    int rowv[ITERS], c8v[ITERS];
+                    f16x8 bvv[ITERS];
+                    auto is_live = [&](int it) { return (16 * VPR) % 64 == 0 || it * 64 + lane < 16 * VPR; };
 #pragma unroll
-                for (int i = 0; i < FM; ++i) {
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        *(f32x4*)(patch + frow * LDP + j * 16 + fks * 4) = acc[i][j];
-                        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int it = 0; it < ITERS; ++it) {
+                        const int idx = it * 64 + lane;
+                        rowv[it] = is_live(it) ? idx / VPR : 0;
+                        c8v[it] = is_live(it) ? (idx - rowv[it] * VPR) * 8 : 0;
+                        const int n = n_w0 + c8v[it];
+                        bvv[it] = *(const f16x8*)(bp + ((FULL || n + 8 <= p.N) ? n : 0) * mbias);
                     }
-                    __builtin_amdgcn_wave_barrier();
-                    if constexpr ((EPI & 8) == 0) {
-                        constexpr bool RB = EPI & 1, R1 = EPI & 2, R2 = EPI & 4;
-                        constexpr int VPR = WN / 8;                 // 16-byte output vectors per row
-                        constexpr int ITERS = (16 * VPR + 63) / 64;
+                    f16x8 rbv[2], q1v[2], q2v[2];
+                    auto fetch = [&](int i, int it, int set) {
+                        const int m = m_w0 + i * 16 + rowv[it], n = n_w0 + c8v[it];
+                        const int mc = FULL ? m : min(m, p.M - 1), nc = (FULL || n + 8 <= p.N) ? n : 0;
+                        if constexpr (RB) rbv[set] = *(const f16x8*)(rbp + (size_t)(mc / p.rows_per_group) * ldrb + nc * mrb);
+                        if constexpr (R1) q1v[set] = *(const f16x8*)(r1p + (size_t)mc * ld1 + nc * m1);
+                        if constexpr (R2) q2v[set] = *(const f16x8*)(r2p + (size_t)mc * ld2 + nc * m2);
+                    };
+                    fetch(0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) {
+                            *(f32x4*)(patch + frow * LDP + j * 16 + fks * 4) = acc[i][j];
+                            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        }
+                        __builtin_amdgcn_wave_barrier();
 #pragma unroll
                         for (int it = 0; it < ITERS; ++it) {
-                            const int idx = it * 64 + lane;
-                            const bool live = (16 * VPR) % 64 == 0 || idx < 16 * VPR;
-                            const int row = live ? idx / VPR : 0, c8 = live ? (idx - row * VPR) * 8 : 0;
+                            const int set = (i * ITERS + it) & 1;
+                            if (it + 1 < ITERS) fetch(i, it + 1, set ^ 1);
+                            else if (i + 1 < FM) fetch(i + 1, 0, set ^ 1);
+                            const int row = rowv[it], c8 = c8v[it];
                             const int m = m_w0 + i * 16 + row, n = n_w0 + c8;
-                            const int mc = FULL ? m : min(m, p.M - 1), nc = (FULL || n + 8 <= p.N) ? n : 0;
                             const f32x4 lo = *(const f32x4*)(patch + row * LDP + c8);
                             const f32x4 hi = *(const f32x4*)(patch + row * LDP + c8 + 4);
-                            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                            const f16x8 bv = *(const f16x8*)(bp + nc * mbias);
-                            f16x8 rbv, q1v, q2v;
-                            if constexpr (RB) rbv = *(const f16x8*)(rbp + (size_t)(mc / p.rows_per_group) * ldrb + nc * mrb);
-                            if constexpr (R1) q1v = *(const f16x8*)(r1p + (size_t)mc * ld1 + nc * m1);
-                            if constexpr (R2) q2v = *(const f16x8*)(r2p + (size_t)mc * ld2 + nc * m2);
+                            const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                             f16x8 o;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
-                                float x = v[e] + (float)bv[e];
-                                if constexpr (RB) x += (float)rbv[e];
+                                float x = v[e] + (float)bvv[it][e];
+                                if constexpr (RB) x += (float)rbv[set][e];
                                 if (p.act == EW_ACT_SILU) x = ew_silu(x);
                                 x *= p.c_acc;
-                                if constexpr (R1) x += p.c_r1 * (float)q1v[e];
-                                if constexpr (R2) x += p.c_r2 * (float)q2v[e];
+                                if constexpr (R1) x += p.c_r1 * (float)q1v[set][e];
+                                if constexpr (R2) x += p.c_r2 * (float)q2v[set][e];
                                 o[e] = (f16)x;
                             }
-                            if (FULL ? live : (live && m < p.M && n + 8 <= p.N && !(p.dbg & 1)))
+                            if (FULL ? is_live(it) : (is_live(it) && m < p.M && n + 8 <= p.N && !(p.dbg & 1)))
                                 *(f16x8*)(p.out + (size_t)m * p.ld_out + n) = o;
-                            else if (!FULL && live && m < p.M && !(p.dbg & 1)) {
+                            else if (!FULL && is_live(it) && m < p.M && !(p.dbg & 1)) {
+#pragma unroll
                                 for (int e = 0; e < 8; ++e)                     // ragged N edge (e.g. conv_out N=4)
                                     if (n + e < p.N) p.out[(size_t)m * p.ld_out + n + e] = o[e];
                             }
                         }
-                    } else {
-                        // GEGLU: staged columns come in blocks of 32 = [16 value | 16 gate]; output has WN/2 columns
-                        constexpr int VPR = WN / 16;                // 16-byte output vectors per row
-                        constexpr int ITERS = (16 * VPR + 63) / 64;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                } else {
+                    // GEGLU: staged columns come in blocks of 32 = [16 value | 16 gate]; output has WN/2 columns
+                    constexpr int VPR = WN / 16;                // 16-byte output vectors per row
+                    constexpr int ITERS = (16 * VPR + 63) / 64;
+                    int rowv[ITERS], ovv[ITERS];
+                    f16x8 bvals[ITERS], bgates[ITERS];
+                    auto is_live = [&](int it) { return (16 * VPR) % 64 == 0 || it * 64 + lane < 16 * VPR; };
+#pragma unroll
+                    for (int it = 0; it < ITERS; ++it) {
+                        const int idx = it * 64 + lane;
+                        rowv[it] = is_live(it) ? idx / VPR : 0;
+                        ovv[it] = is_live(it) ? idx - rowv[it] * VPR : 0;
+                        const int ns = n_w0 + (ovv[it] >> 1) * 32 + (ovv[it] & 1) * 8;
+                        const int nsc = (FULL || ns < p.N) ? ns : 0;
+                        bvals[it] = *(const f16x8*)(bp + nsc * mbias);
+                        bgates[it] = *(const f16x8*)(bp + (nsc + 16) * mbias);
+                    }
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) {
+                            *(f32x4*)(patch + frow * LDP + j * 16 + fks * 4) = acc[i][j];
+                            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        }
+                        __builtin_amdgcn_wave_barrier();
 #pragma unroll
                         for (int it = 0; it < ITERS; ++it) {
-                            const int idx = it * 64 + lane;
-                            const bool live = (16 * VPR) % 64 == 0 || idx < 16 * VPR;
-                            const int row = live ? idx / VPR : 0, ov = live ? idx - row * VPR : 0;
-                            const int q = ov >> 1, c = (ov & 1) * 8;                 // 32-column block q, 8 columns at c
+                            const int row = rowv[it], q = ovv[it] >> 1, c = (ovv[it] & 1) * 8;
                             const int m = m_w0 + i * 16 + row;
                             const int ns = n_w0 + q * 32 + c;                       // staged column of the value
-                            const int nsc = (FULL || ns < p.N) ? ns : 0;          // out-of-range columns only ever feed discarded lanes
                             const float* pr = patch + row * LDP + q * 32 + c;
                             const f32x4 v0 = *(const f32x4*)(pr), v1 = *(const f32x4*)(pr + 4);
                             const f32x4 g0 = *(const f32x4*)(pr + 16), g1 = *(const f32x4*)(pr + 20);
-                            const f16x8 bvv = *(const f16x8*)(bp + nsc * mbias), bgg = *(const f16x8*)(bp + (nsc + 16) * mbias);
                             const float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                             const float gg[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
                             f16x8 o;
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] = (f16)((vv[e] + (float)bvv[e]) * ew_gelu(gg[e] + (float)bgg[e]));
+                            for (int e = 0; e < 8; ++e)
+                                o[e] = (f16)((vv[e] + (float)bvals[it][e]) * ew_gelu(gg[e] + (float)bgates[it][e]));
                             const int no = (n_w0 >> 1) + q * 16 + c;
-                            if (FULL ? live : (live && m < p.M && ns < p.N && !(p.dbg & 1)))
+                            if (FULL ? is_live(it) : (is_live(it) && m < p.M && ns < p.N && !(p.dbg & 1)))
                                 *(f16x8*)(p.out + (size_t)m * p.ld_out + no) = o;
                         }
+                        __builtin_amdgcn_wave_barrier();
                     }
-                    __builtin_amdgcn_wave_barrier();
                 }
             };
             if (p.dbg & 2) {

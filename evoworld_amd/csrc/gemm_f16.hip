@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
 
     auto stage = [&](int kt, char* buf) {
         const int tap = st_tap, cc = st_cc;
-        st_cc += BK;
-        if (st_cc == C) { st_cc = 0; ++st_tap; }
+        const int ntap = p.mode == EW_A_CONV3X3 ? 9 : (p.mode == EW_A_CONVT3 ? 3 : 1);   // chunk-major, tap-minor K order
+        if (++st_tap == ntap) { st_tap = 0; st_cc += BK; }
         const bool second = cc >= p.c1;
         const int key = tap * 2 + (second ? 1 : 0);
         if (key != cur_key) {              // wave-uniform branch: new tap or switch to the concat source

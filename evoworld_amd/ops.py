@@ -224,3 +224,16 @@ def u8_hwc_to_f32_chw(src):
     dst = torch.empty(V, 3, H, W, dtype=torch.float32, device=src.device)
     _lib.check(lib.ew_u8_hwc_to_f32_chw(_ptr(src), _ptr(dst), V, H, W, _stream()), "ew_u8_hwc_to_f32_chw")
     return dst
+
+
+def pack_conv_weight(w, cpad=None):
+    """[O, I, *taps] (Conv2d 3x3 / Conv3d (3,1,1)) fp32 -> fp16 [O, K] in the K order ew_gemm_f16's conv modes read:
+    [I/64 chunks][taps][64 channels].  `cpad` zero-pads the input channels first (conv_in: 18 -> 64)."""
+    O, I = w.shape[0], w.shape[1]
+    wt = w.reshape(O, I, -1).permute(0, 2, 1)                       # [O, taps, I]
+    if cpad:
+        wt = torch.nn.functional.pad(wt, (0, cpad - I))
+        I = cpad
+    taps = wt.shape[1]
+    wt = wt.reshape(O, taps, I // 64, 64).permute(0, 2, 1, 3)       # [O, chunks, taps, 64]
+    return wt.reshape(O, -1).to(torch.float16).contiguous()

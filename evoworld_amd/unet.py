@@ -284,15 +284,11 @@ class UNetSpatioTemporalConditionModel:
         def h(t):
             return t.to(torch.float16).contiguous()
 
-        def conv3(k, cpad=None):   # [O,I,3,3] -> [O, 9*I] tap-major
-            w = f32(k + ".weight").permute(0, 2, 3, 1)
-            if cpad:
-                w = torch.nn.functional.pad(w, (0, cpad - w.shape[-1]))
-            return h(w.reshape(w.shape[0], -1))
+        def conv3(k, cpad=None):   # [O,I,3,3] -> [O, K], K = [I/64][9][64]
+            return ops.pack_conv_weight(f32(k + ".weight"), cpad)
 
-        def convt(k):              # [O,I,3,1,1] -> [O, 3*I]
-            w = f32(k + ".weight")[:, :, :, 0, 0].permute(0, 2, 1)
-            return h(w.reshape(w.shape[0], -1))
+        def convt(k):              # [O,I,3,1,1] -> [O, K], K = [I/64][3][64]
+            return ops.pack_conv_weight(f32(k + ".weight"))
 
         def geglu(k):              # interleave value/gate rows in blocks of 16 (see ew_gemm_f16)
             w, b = f32(k + ".weight"), f32(k + ".bias")

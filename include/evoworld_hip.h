@@ -33,16 +33,18 @@ const char* ew_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused MFMA GEMM / implicit-GEMM convolution  (fp16 in, fp32 accumulate, fp16 out).
- *   acc[m][n] = sum_k A(m,k) * W[n][k]                    W row-major [N, K], K = taps*(c1+c2)
+ *   acc[m][n] = sum_k A(m,k) * W[n][k]                    W row-major [N, K], K = taps*(c1+c2); in the conv modes the K axis
+ *                                                         is ordered [channel chunk of 64][tap][64 channels] (chunk-major,
+ *                                                         tap-minor: the taps of a chunk re-hit its input lines in L2)
  *   v   = acc + bias[n] + rowbias[(m / rows_per_group) * ld_rowbias + n]
  *   v   = act(v)            act 0: none; 1: SiLU; 2: GEGLU -> out has N/2 columns (see w layout note below)
  *   out = c_acc*v + c_r1*r1[m][n] + c_r2*r2[m][n]
  * A-operand addressing modes (the gather happens in the global->LDS DMA address, no im2col buffer):
  *   EW_A_DENSE   A(m, k)          = a[m*lda + k]                      (k < c1; then a2[m*lda2 + k-c1])
  *   EW_A_CONV3X3 m -> (img, oy, ox) on an [n_img, h_out, w_out] grid; tap = ky*3+kx;
- *                A(m, tap*C + c)  = in[img, iy, ix, c], iy = oy*stride+ky-1, ix = ox*stride+kx-1, zero
+ *                A(m, (tap, c))   = in[img, iy, ix, c], iy = oy*stride+ky-1, ix = ox*stride+kx-1, zero
  *                outside; with upsample=1 the input is read as nearest-x2 upsampled ([h_in,w_in] -> 2x).
- *   EW_A_CONVT3  m -> (b, t, p) on a [B, T, P] grid; A(m, kt*C + c) = in[b, t+kt-1, p, c], zero outside.
+ *   EW_A_CONVT3  m -> (b, t, p) on a [B, T, P] grid; A(m, (kt, c)) = in[b, t+kt-1, p, c], zero outside.
  * In the conv modes channels [0,c1) come from `a`, [c1,c1+c2) from `a2` (the up-block skip concat,
  * evoworld/trainer/unet_plucker.py:458-475 + diffusers up blocks) without materialising the concat.
  * Replaces: torch.nn.Linear / Conv2d / Conv3d(3,1,1) calls inside the diffusers blocks instantiated at

@@ -97,8 +97,9 @@ def _nhwc(x):  # [N,C,H,W] -> [N*H*W, C] fp16
     return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).half().contiguous().to(DEV)
 
 
-def _pack3(w):  # [O,I,3,3] -> [O, 9I]
-    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).half().contiguous().to(DEV)
+def _pack3(w):  # [O,I,3,3] -> [O, K] in the kernel's chunk-major / tap-minor K order
+    from evoworld_amd.ops import pack_conv_weight
+    return pack_conv_weight(w.half().float()).to(DEV)
 
 
 @pytest.mark.parametrize("N,C,O,H,W,stride,up", [(3, 64, 160, 9, 16, 1, 0), (2, 128, 128, 18, 32, 2, 0),
@@ -133,7 +134,7 @@ def test_conv_temporal(ops, B, T, P, C):
     w, b = rnd(C, C, 3, 1, 1, seed=2) / math.sqrt(3 * C), rnd(C, seed=3)
     xr = x.half().float().permute(0, 3, 1, 2).unsqueeze(-1)           # [B,C,T,P,1]
     ref = F.conv3d(xr.to(DEV), w.half().float().to(DEV), b.half().float().to(DEV), padding=(1, 0, 0))
-    wp = w[:, :, :, 0, 0].permute(0, 2, 1).reshape(C, 3 * C).half().contiguous().to(DEV)
+    wp = _pack3(w)
     out = torch.empty(B * T * P, C, dtype=torch.float16, device=DEV)
     ops.gemm(x.reshape(-1, C).half().to(DEV), wp, out, M=B * T * P, N=C, c1=C, lda=C, bias=b.half().to(DEV),
              mode=ops.A_CONVT3, tconv=(B, T, P))

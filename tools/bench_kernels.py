@@ -41,7 +41,7 @@ def report(name, ms, flops=None, bytes_=None):
 
 
 def gemm_case(name, M, N, K, act=0, res=False):
-    if FILTER and FILTER not in name:
+    if FILTER and FILTER not in "gemm " + name:
         return
     x, w, b = rnd(M, K), rnd(N, K) * 0.05, rnd(N)
     out = torch.empty(M, N // 2 if act == 2 else N, dtype=torch.float16, device=DEV)
@@ -51,7 +51,7 @@ def gemm_case(name, M, N, K, act=0, res=False):
 
 
 def conv_case(name, N, C, O, H, W, stride=1, up=0, c2=0):
-    if FILTER and FILTER not in name:
+    if FILTER and FILTER not in "conv3x3 " + name:
         return
     x = rnd(N * H * W, C)
     x2 = rnd(N * H * W, c2) if c2 else None
@@ -64,7 +64,7 @@ def conv_case(name, N, C, O, H, W, stride=1, up=0, c2=0):
 
 
 def convt_case(name, B, T, P, C):
-    if FILTER and FILTER not in name:
+    if FILTER and FILTER not in "convT3 " + name:
         return
     x, w, b = rnd(B * T * P, C), rnd(C, 3 * C) * 0.02, rnd(C)
     out = torch.empty(B * T * P, C, dtype=torch.float16, device=DEV)
@@ -73,7 +73,7 @@ def convt_case(name, B, T, P, C):
 
 
 def attn_case(name, n_seq, S, heads):
-    if FILTER and FILTER not in name:
+    if FILTER and FILTER not in "attn_spatial " + name:
         return
     C = heads * 64
     rows = n_seq * S
@@ -84,7 +84,7 @@ def attn_case(name, n_seq, S, heads):
 
 
 def attn_t_case(name, B, T, S, heads):
-    if FILTER and FILTER not in name:
+    if FILTER and FILTER not in "attn_temporal " + name:
         return
     C = heads * 64
     rows = B * T * S

@@ -1,0 +1,11 @@
+import os, sys, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.argv = [sys.argv[0]]
+from evoworld_amd import _lib
+import tools.bench_kernels as B
+lib = _lib.load()
+for dbg, name in ((0, "normal"), (2, "no epilogue"), (2 | 128, "no epilogue, no DMA"), (2 | 256, "no epilogue, no frag reads"), (2 | 128 | 256, "MFMA + barriers only")):
+    lib.ew_set_gemm_debug(dbg); print("##", name)
+    B.conv_case("L0 320", 50, 320, 320, 72, 128)
+    B.conv_case("L2 1280", 50, 1280, 1280, 18, 32)
+    B.gemm_case("L2 ff_down", 28800, 1280, 5120, res=True)
