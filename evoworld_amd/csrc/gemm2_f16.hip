@@ -39,6 +39,8 @@ __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 7) EW_WAIT_VMCNT(7);
     else if constexpr (N == 8) EW_WAIT_VMCNT(8);
     else if constexpr (N == 10) EW_WAIT_VMCNT(10);
+    else if constexpr (N == 12) EW_WAIT_VMCNT(12);
+    else if constexpr (N == 16) EW_WAIT_VMCNT(16);
     else if constexpr (N == 14) EW_WAIT_VMCNT(14);
     else if constexpr (N == 18) EW_WAIT_VMCNT(18);
     else if constexpr (N == 19) EW_WAIT_VMCNT(19);
@@ -392,46 +394,42 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
                         __builtin_amdgcn_wave_barrier();
                     }
                 } else {
-                    // GEGLU: staged columns come in blocks of 32 = [16 value | 16 gate]; output has WN/2 columns
-                    constexpr int VPR = WN / 16;                // 16-byte output vectors per row
+                    // GEGLU: staged column blocks of 32 = [16 value | 16 gate] -> fragment 2q holds values, 2q+1 the gates of
+                    // the SAME (row, column) positions in the SAME lane: value*gelu(gate) is formed in registers, only the
+                    // WN/2 output columns go through the (half-width) patch, and a row's output is one contiguous run.
+                    constexpr int WO = WN / 2, LDO = WO + 4;
+                    constexpr int VPR = WO / 8;                 // 16-byte output vectors per row
                     constexpr int ITERS = (16 * VPR + 63) / 64;
-                    int rowv[ITERS], ovv[ITERS];
-                    f16x8 bvals[ITERS], bgates[ITERS];
-                    auto is_live = [&](int it) { return (16 * VPR) % 64 == 0 || it * 64 + lane < 16 * VPR; };
+                    f32x4 bq[FN];
 #pragma unroll
-                    for (int it = 0; it < ITERS; ++it) {
-                        const int idx = it * 64 + lane;
-                        rowv[it] = is_live(it) ? idx / VPR : 0;
-                        ovv[it] = is_live(it) ? idx - rowv[it] * VPR : 0;
-                        const int ns = n_w0 + (ovv[it] >> 1) * 32 + (ovv[it] & 1) * 8;
-                        const int nsc = (FULL || ns < p.N) ? ns : 0;
-                        bvals[it] = *(const f16x8*)(bp + nsc * mbias);
-                        bgates[it] = *(const f16x8*)(bp + (nsc + 16) * mbias);
+                    for (int j = 0; j < FN; ++j) {
+                        const int n = n_w0 + j * 16 + fks * 4;
+                        const f16x4 b4 = *(const f16x4*)(bp + ((FULL || n < p.N) ? n : 0) * mbias);
+                        bq[j] = (f32x4){(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
                     }
+                    auto is_live = [&](int it) { return (16 * VPR) % 64 == 0 || it * 64 + lane < 16 * VPR; };
 #pragma unroll
                     for (int i = 0; i < FM; ++i) {
 #pragma unroll
-                        for (int j = 0; j < FN; ++j) {
-                            *(f32x4*)(patch + frow * LDP + j * 16 + fks * 4) = acc[i][j];
-                            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        for (int q = 0; q < FN / 2; ++q) {
+                            const f32x4 vv = acc[i][2 * q] + bq[2 * q], gg = acc[i][2 * q + 1] + bq[2 * q + 1];
+                            f32x4 o4;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o4[e] = vv[e] * ew_gelu(gg[e]);
+                            *(f32x4*)(patch + frow * LDO + q * 16 + fks * 4) = o4;
+                            acc[i][2 * q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            acc[i][2 * q + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
                         }
                         __builtin_amdgcn_wave_barrier();
 #pragma unroll
                         for (int it = 0; it < ITERS; ++it) {
-                            const int row = rowv[it], q = ovv[it] >> 1, c = (ovv[it] & 1) * 8;
+                            const int idx = it * 64 + lane;
+                            const int row = is_live(it) ? idx / VPR : 0, c8 = is_live(it) ? (idx - row * VPR) * 8 : 0;
                             const int m = m_w0 + i * 16 + row;
-                            const int ns = n_w0 + q * 32 + c;                       // staged column of the value
-                            const float* pr = patch + row * LDP + q * 32 + c;
-                            const f32x4 v0 = *(const f32x4*)(pr), v1 = *(const f32x4*)(pr + 4);
-                            const f32x4 g0 = *(const f32x4*)(pr + 16), g1 = *(const f32x4*)(pr + 20);
-                            const float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                            const float gg[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-                            f16x8 o;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e)
-                                o[e] = (f16)((vv[e] + (float)bvals[it][e]) * ew_gelu(gg[e] + (float)bgates[it][e]));
-                            const int no = (n_w0 >> 1) + q * 16 + c;
-                            if (FULL ? is_live(it) : (is_live(it) && m < p.M && ns < p.N && !(p.dbg & 1)))
+                            const f32x4 lo = *(const f32x4*)(patch + row * LDO + c8), hi = *(const f32x4*)(patch + row * LDO + c8 + 4);
+                            const f16x8 o = {(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
+                            const int no = (n_w0 >> 1) + c8;
+                            if (FULL ? is_live(it) : (is_live(it) && m < p.M && 2 * no < p.N && !(p.dbg & 1)))
                                 *(f16x8*)(p.out + (size_t)m * p.ld_out + no) = o;
                         }
                         __builtin_amdgcn_wave_barrier();
@@ -486,6 +484,7 @@ ew_status dispatch_tile(const GemmP& p, hipStream_t s) {
     const bool v1 = (p.dbg & 16) != 0;
     if constexpr (EPI & 8) {
         if (v1) return launch2<128, 128, 2, 2, 2, MODE, EPI>(p, s);
+        // (a 256x256 / 2-stage GEGLU tile was measured 15-25 % slower: 41 spilled VGPRs, shallower ring)
         return launch2<128, 256, 2, 4, 3, MODE, EPI>(p, s);
     } else {
         if (p.N % 160 == 0) {
