@@ -143,3 +143,31 @@ def test_process_episode_on_device_chain(tiny):
     pano = R.cube2equi_gather_ref(faces, R.cube2equi_lut_ref(128, 64, 32))
     want = torch.stack([(torch.tensor(np.array(Image.fromarray(pp).resize((W, H), Image.BILINEAR))).permute(2, 0, 1).float() / 255) * 2 - 1 for pp in pano])
     assert torch.equal(mems[1][1:].cpu(), want)
+
+
+def test_cli_entry_point_two_segments(tmp_path):
+    """The reference's CLI (unified_loop_consistency.py flags) on a tiny checkpoint written in the diffusers folder layout:
+    from_pretrained -> 2 segments with evolving memory -> 49 frames, PNG dumps, memory panoramas for segment 1."""
+    import json, os
+    from safetensors.torch import save_file
+    from evoworld_amd.unet import DEFAULT_CONFIG, random_state_dict
+    from oracle.unet_ref import tiny_config
+    import unified_loop_consistency as cli
+    cfg = tiny_config()
+    cfg["num_frames"] = 25
+    ck = tmp_path / "ckpt" / "unet"
+    ck.mkdir(parents=True)
+    json.dump({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, open(ck / "config.json", "w"))
+    save_file({k: v.contiguous() for k, v in random_state_dict({**DEFAULT_CONFIG, **cfg}, 0).items()}, str(ck / "diffusion_pytorch_model.safetensors"))
+    ep = tmp_path / "data" / "case_000"
+    ep.mkdir(parents=True)
+    with open(ep / "camera_poses.txt", "w") as f:
+        f.write("Frame,PosX,PosY,PosZ,RotX,RotY,RotZ\n")
+        for i in range(60):
+            f.write(f"{i + 1},{0.05 * i},1.78,{15 - 0.03 * i},0.0,{95 + 2.0 * i},0.0\n")
+    cam = cli.load_camera_poses(str(ep))
+    assert cam.shape == (60, 6) and cam[0, 1] == -1.78 and cam[1, 4] == 97.0
+    rep = cli.main(["--unet_path", str(tmp_path / "ckpt"), "--base_folder", str(tmp_path / "data"), "--save_dir", str(tmp_path / "out"),
+                    "--num_segments", "2", "--num_inference_steps", "1", "--height", "128", "--width", "256", "--save_frames", "--curve_path"])
+    assert rep == [{"episode": "case_000", "frames": 49, "seconds": rep[0]["seconds"], "rank": 0}]
+    assert len(os.listdir(tmp_path / "out" / "case_000" / "predictions")) == 49
