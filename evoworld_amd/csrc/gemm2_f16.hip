@@ -29,28 +29,14 @@ namespace {
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-    if constexpr (N == 0) EW_WAIT_VMCNT(0);
-    else if constexpr (N == 1) EW_WAIT_VMCNT(1);
-    else if constexpr (N == 2) EW_WAIT_VMCNT(2);
-    else if constexpr (N == 3) EW_WAIT_VMCNT(3);
-    else if constexpr (N == 4) EW_WAIT_VMCNT(4);
-    else if constexpr (N == 5) EW_WAIT_VMCNT(5);
-    else if constexpr (N == 6) EW_WAIT_VMCNT(6);
-    else if constexpr (N == 7) EW_WAIT_VMCNT(7);
-    else if constexpr (N == 8) EW_WAIT_VMCNT(8);
-    else if constexpr (N == 10) EW_WAIT_VMCNT(10);
-    else if constexpr (N == 12) EW_WAIT_VMCNT(12);
-    else if constexpr (N == 16) EW_WAIT_VMCNT(16);
-    else if constexpr (N == 14) EW_WAIT_VMCNT(14);
-    else if constexpr (N == 18) EW_WAIT_VMCNT(18);
-    else if constexpr (N == 19) EW_WAIT_VMCNT(19);
-    else static_assert(N < 0, "extend wait_vmcnt");
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // EPI: compile-time epilogue operand set -- bit0 row-bias, bit1 residual r1, bit2 residual r2, bit3 GEGLU.  An operand
 // that is compiled in but absent at run time is read from the zero page with stride 0 (so a superset kernel is always valid).
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, int EPI>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const GemmP p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && BM == 256) ? 1 : 2) void gemm2_kernel(const GemmP p) {
     constexpr int NW = WAVES_M * WAVES_N;                  // 8 waves, 1 workgroup/CU  -or-  4 waves, 2 workgroups/CU
     constexpr int BK = 64;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -61,7 +47,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
     constexpr int GB_FULL = B_GROUPS / NW;                 // W row-groups every wave owns
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int A_BYTES = BM * 128;
-    static_assert((NW == 8 || NW == 4) && WM == 64 && A_GROUPS % NW == 0 && (NSTAGE == 2 || NSTAGE == 3), "config");
+    static_assert((NW == 8 || NW == 4) && (WM == 64 || WM == 128) && A_GROUPS % NW == 0 && (NSTAGE == 2 || NSTAGE == 3), "config");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -90,12 +76,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
     // centre + a wave-uniform tap delta: ~5 VALU per row per K-tile, no re-derivation of (img, y, x) inside the stream
     // (an ablation showed the loader's address arithmetic, not DMA bandwidth, was costing ~30 % of the main loop).
     int ld_i = 0, ld_kt = 0, ld_tap = 0, ld_cc = 0;
-    long long a_off1[GA], a_off2[GA];
+    int a_ctr[GA];                         // centre-tap pixel (row) index in the source tensors
     int a_mask[GA];                        // bits 0..8 tap validity, bits 16..27 upsample (dy,dx) codes
     const f16* b_ptr[GB];
     constexpr int NTAP = MODE == EW_A_CONV3X3 ? 9 : (MODE == EW_A_CONVT3 ? 3 : 1);
 
-    auto loader_new_tile = [&]() {
+    auto loader_new_tile = [&]() __attribute__((always_inline)) {
         const int id = ld_i * G + seq0;
         const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
         const int m0 = tm * BM, n0 = tn * BN;
@@ -138,8 +124,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
                 ctr = m;
             }
             a_mask[i] = mask | (dcode << 16);
-            a_off1[i] = ctr * p.lda + slot * 8;
-            a_off2[i] = ctr * p.lda2 + slot * 8;
+            a_ctr[i] = (int)ctr;
         }
 #pragma unroll
         for (int j = 0; j < GB; ++j) {
@@ -150,43 +135,62 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
         ld_kt = 0; ld_tap = 0; ld_cc = 0;
     };
 
-    auto stage = [&](char* buf) {   // issue the DMA of the next K-tile of the stream into ring slot `buf`
+    // Staging of one K-tile = stage_begin (wave-uniform source selection, advances the stream counters) + NP DMA pieces.
+    // In the steady state the pieces are INTERLEAVED with the MFMAs (mma_il below): issuing an LDS-DMA instruction costs the
+    // issuing wave ~60-180 cycles, and with all pieces issued back to back after the barrier both waves of a SIMD sat in
+    // DMA issue at the same time with the MFMA pipe idle (exp10: ~650 of ~2500 cycles per K-tile).
+    constexpr int NP = GA + GB;                                             // pieces per K-tile (the last W piece may be absent)
+    constexpr int P0 = NP / 2;                                              // pieces [0,P0) ride half-step 1, [P0,NP) the next half-step 0
+    const f16* st_base = p.a;
+    const f16* st_zp = p.zero_page + slot * 8;
+    long long st_dl = 0;
+    bool st_second = false;
+    int st_tap = 0, st_ld = 0, st_ch = 0;
+    size_t st_koff = 0;
+    char* st_buf = smem;
+    auto stage_begin = [&](char* buf) __attribute__((always_inline)) {
         if (ld_kt == 0) loader_new_tile();
-        const int tap = ld_tap, cc = ld_cc;
-        const bool second = cc >= p.c1;
-        const f16* base = second ? p.a2 : p.a;
-        const int ld = second ? p.lda2 : p.lda;
-        const int ch = second ? cc - p.c1 : cc;
+        st_buf = buf;
+        st_tap = ld_tap;
+        const int cc = ld_cc;
+        st_second = cc >= p.c1;
+        st_base = st_second ? p.a2 : p.a;
+        st_ld = st_second ? p.lda2 : p.lda;
+        st_ch = st_second ? cc - p.c1 : cc;
         int dpix = 0;                                                       // wave-uniform tap delta in pixels
-        if constexpr (MODE == EW_A_CONV3X3) dpix = (tap / 3 - 1) * p.w_in + (tap % 3 - 1);
-        else if constexpr (MODE == EW_A_CONVT3) dpix = (tap - 1) * p.tP;
-        const long long dl = (long long)dpix * ld + ch;
-        const f16* zp = p.zero_page + slot * 8;
-#pragma unroll
-        for (int i = 0; i < GA; ++i) {
-            const long long off = second ? a_off2[i] : a_off1[i];
-            const f16* src = base + off + dl;
-            if constexpr (MODE == EW_A_CONV3X3) {
-                if (p.upsample) {                                           // per-row deltas (nearest-x2 source coordinates)
-                    const int dc = a_mask[i] >> 16;
-                    const int dy = ((dc >> (2 * (tap / 3))) & 3) - 1, dx = ((dc >> (6 + 2 * (tap % 3))) & 3) - 1;
-                    src = base + off + ((long long)(dy * p.w_in + dx) * ld + ch);
-                }
-            }
-            if constexpr (MODE != EW_A_DENSE) src = ((a_mask[i] >> tap) & 1) ? src : zp;
-            glds16(src, buf + (wave + NW * i) * 1024);
-        }
-        const size_t koff = (size_t)ld_kt * BK;
-#pragma unroll
-        for (int j = 0; j < GB_FULL; ++j) glds16(b_ptr[j] + koff, buf + A_BYTES + (wave + NW * j) * 1024);
-        if constexpr (GB > GB_FULL) {
-            if (has_tail) glds16(b_ptr[GB - 1] + koff, buf + A_BYTES + (wave + NW * (GB - 1)) * 1024);
-        }
+        if constexpr (MODE == EW_A_CONV3X3) dpix = (st_tap / 3 - 1) * p.w_in + (st_tap % 3 - 1);
+        else if constexpr (MODE == EW_A_CONVT3) dpix = (st_tap - 1) * p.tP;
+        st_dl = (long long)dpix * st_ld + st_ch;
+        st_koff = (size_t)ld_kt * BK;
         // K order is CHANNEL-CHUNK major, tap minor: the taps of one 64-channel chunk re-read (shifted) the same input
         // lines, so the chunk's footprint (~66 KB per workgroup) is fetched from HBM/MALL once and re-hit in L2 for the
         // other taps; tap-major order re-fetched the whole C-wide footprint (10 MB per XCD > 4 MB L2) for every tap.
         if (++ld_tap == NTAP) { ld_tap = 0; ld_cc += BK; }
         if (++ld_kt == nk) { ld_kt = 0; ++ld_i; }
+    };
+    auto stage_piece = [&](int k) __attribute__((always_inline)) {     // k is a compile-time constant after unrolling
+        if (k < GA) {
+            const int i = k;
+            // element offset = centre row * row stride + (tap delta + channel + this lane's 16-byte slot): one v_mad_u64_u32
+            const f16* src = st_base + ((long long)a_ctr[i] * st_ld + (st_dl + slot * 8));
+            if constexpr (MODE == EW_A_CONV3X3) {
+                if (p.upsample) {                                           // per-row deltas (nearest-x2 source coordinates)
+                    const int dc = a_mask[i] >> 16;
+                    const int dy = ((dc >> (2 * (st_tap / 3))) & 3) - 1, dx = ((dc >> (6 + 2 * (st_tap % 3))) & 3) - 1;
+                    src = st_base + ((long long)(a_ctr[i] + dy * p.w_in + dx) * st_ld + (st_ch + slot * 8));
+                }
+            }
+            if constexpr (MODE != EW_A_DENSE) src = ((a_mask[i] >> st_tap) & 1) ? src : st_zp;
+            glds16(src, st_buf + (wave + NW * i) * 1024);
+        } else {
+            const int j = k - GA;
+            if (j < GB_FULL || has_tail) glds16(b_ptr[j] + st_koff, st_buf + A_BYTES + (wave + NW * j) * 1024);
+        }
+    };
+    auto stage = [&](char* buf) __attribute__((always_inline)) {       // whole K-tile at once (prologue, and the DMA deferred past an epilogue)
+        stage_begin(buf);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) stage_piece(k);
     };
 
     // Output stores issued by this wave in one FULL-tile epilogue (exact instruction count: every store executes).
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
     // own DMA of the NEXT K-tile landed; the newest K-tile (n_ld DMA instructions) stays in flight.  `stores_behind`:
     // the NST output stores of the tile just finished were issued AFTER the DMA we wait for -- vmcnt counts in issue
     // order, so they are allowed to stay in flight too and the wave does not stall on store acknowledgements.
-    auto wait_landed = [&](bool more_in_flight, bool stores_behind) {
+    auto wait_landed = [&](bool more_in_flight, bool stores_behind) __attribute__((always_inline)) {
         if constexpr (NSTAGE == 2) { wait_vmcnt<0>(); return; }         // nothing newer than the tile we wait for
         else {
             if (!more_in_flight) { wait_vmcnt<0>(); return; }
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     f16x8 af0[FM], bf0[FN], af1[FM], bf1[FN];
-    auto read_frags = [&](const char* buf, int so, f16x8 (&af)[FM], f16x8 (&bf)[FN]) {
+    auto read_frags = [&](const char* buf, int so, f16x8 (&af)[FM], f16x8 (&bf)[FN]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) bf[j] = *(const f16x8*)(buf + b_off[j] + so);
 #pragma unroll
@@ -237,6 +241,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // D[n][m]
     };
 
+    // MFMAs of one half-step with DMA pieces [LO,HI) of the pending stage spread evenly between them
+    auto mma_il = [&](const f16x8 (&af)[FM], const f16x8 (&bf)[FN], bool on, auto lo_tag, auto hi_tag) __attribute__((always_inline)) {
+        constexpr int LO = decltype(lo_tag)::value, HI = decltype(hi_tag)::value, NQ = HI - LO, NM = FM * FN;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // D[n][m]
+                const int idx = i * FN + j;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    if (idx == ((q + 1) * NM) / (NQ + 1) - 1) {
+                        if (on) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            stage_piece(LO + q);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+            }
+    };
+
     if (p.dbg & 64) {
         // Chip-wide phase staggering: persistent workgroups that start together stay in lock-step over the WHOLE chip (same
         // tile shape, same duration), so HBM sees all 256 store-bound epilogues at once and idles during the MFMA phases.
@@ -245,7 +270,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
         const int mine = (int)(((blockIdx.x * 97u) & 255u) * (unsigned)period) >> 8;
         for (int i = 0; i < mine; ++i) __builtin_amdgcn_s_sleep(1);
     }
-    if constexpr (NW == 4) {
+    if constexpr (NW == 4 && BM < 256) {
         // Two 4-wave workgroups share a CU.  Started together they stay in lock-step (same tile shape, same duration) and hit
         // their store-bound epilogues at the same time; delaying the second half of the grid by ~half a tile makes one
         // group's epilogue coincide with the other's MFMA phase.  (s_sleep 1 = 64 cycles; a K-tile is ~1300 cycles here.)
@@ -273,6 +298,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
     int cur_i = 0, cur_kt = 0;
     bool stores_behind = false;                      // a full-tile epilogue's stores are newer than the DMA waited next
     int s_cur = 0;                                   // ring slot of stream position v
+    bool pend = false;                               // pieces [P0,NP) of the newest stage still to be issued
     for (int v = 0; v < V; ++v) {
         const int s_nxt = s_cur == NSTAGE - 1 ? 0 : s_cur + 1;
         const char* cur = smem + s_cur * STAGE;
@@ -282,7 +308,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
                            // without waiting for the reads issued next (hipcc otherwise emits lgkmcnt(0) after them)
         read_frags(cur, so1, af1, bf1);
         __builtin_amdgcn_sched_barrier(0);   // keep the reads AHEAD of the MFMAs (hipcc otherwise sinks them to the end)
-        mma(af0, bf0);
+        mma_il(af0, bf0, pend, std::integral_constant<int, P0>{}, std::integral_constant<int, NP>{});
+        pend = false;
         // ---- publish K-tile v+1.  Unconditional (also on the last position, where the fragments read from the ring are
         // stale and never used): a conditional here makes hipcc put a conservative lgkmcnt(0) at the join, in front of
         // the half-step-1 MFMAs, which would expose the LDS latency of the reads just issued.
@@ -293,10 +320,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
         __builtin_amdgcn_s_barrier();
         EW_COMPILER_FENCE();
         read_frags(smem + s_nxt * STAGE, so0, af0, bf0);
-        if (!tile_end && staged < V) { stage(smem + s_cur * STAGE); ++staged; }   // slot of v is free from here on
+        const bool st_now = !tile_end && staged < V;                             // slot of v is free from here on
+        if (st_now) {
+            ++staged;
+            stage_begin(smem + s_cur * STAGE);
+            pend = true;
+        }
         __builtin_amdgcn_sched_barrier(0);
         // ---- half-step 1
-        mma(af1, bf1);
+        mma_il(af1, bf1, st_now, std::integral_constant<int, 0>{}, std::integral_constant<int, P0>{});
         const int s_prev = s_cur;
         s_cur = s_nxt;
         if (++cur_kt == nk) {
@@ -316,7 +348,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm2_kernel(const 
             constexpr int LDP = WN + 4;                            // patch row stride (floats)
             float* patch = (float*)(smem + s_prev * STAGE) + wave * (16 * LDP);
             const int m_w0 = tm * BM + wm * WM, n_w0 = tn * BN + wn * WN;
-            auto epilogue = [&](auto full_tag) {
+            auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
                 constexpr bool FULL = decltype(full_tag)::value;   // FULL: no per-access guards -> exact store count
                 // an operand compiled in (EPI) but absent at run time reads the zero page with stride 0
                 const f16* bp = p.bias ? p.bias : p.zero_page;
@@ -470,7 +502,7 @@ ew_status launch2(const GemmP& p, hipStream_t s) {
     }
     const long long tiles = (long long)q.tiles_m * q.tiles_n;
     if (tiles <= 0 || tiles > 0x7fffffffLL) { ew_set_error("ew_gemm_f16: bad grid"); return EW_ERR_INVALID_ARG; }
-    int grid = NW == 8 ? 256 : 512;                   // persistent: 1 x 8-wave or 2 x 4-wave workgroups per CU (256 CUs)
+    int grid = (NW == 8 || BM == 256) ? 256 : 512;                   // persistent: 1 x 8-wave or 2 x 4-wave workgroups per CU (256 CUs)
     if (tiles < grid) grid = (int)((tiles + 7) / 8 * 8);
     hipLaunchKernelGGL((gemm2_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE, MODE, EPI>), dim3(grid), dim3(64 * NW), lds, s, q);
     return ew_check_launch("ew_gemm_f16(gen2)");
@@ -488,7 +520,7 @@ ew_status dispatch_tile(const GemmP& p, hipStream_t s) {
         return launch2<128, 256, 2, 4, 3, MODE, EPI>(p, s);
     } else {
         if (p.N % 160 == 0) {
-            if (v1) return launch2<128, 160, 2, 2, 2, MODE, EPI>(p, s);
+            if (v1) return launch2<256, 160, 2, 2, 3, MODE, EPI>(p, s);   // 4 waves x (128x80), one wave per SIMD, 512 VGPRs
             return launch2<256, 160, 4, 2, 3, MODE, EPI>(p, s);
         }
         if (v1) return launch2<128, 128, 2, 2, 2, MODE, EPI>(p, s);
