@@ -1,0 +1,412 @@
+// gemm3_f16.hip -- third-generation fused MFMA GEMM / implicit-GEMM conv for gfx950: 256x320 output tile per workgroup.
+//
+// Why (tools/experiments/exp13..16): generation 2's dense GEMMs run exactly as fast with their MFMAs and
+// ds_reads compiled out -- they are bound by the LDS-DMA feed (global_load_lds_dwordx4), which saturates at ~50-54 GB/s per
+// CU (~13.5 TB/s over the chip) for L2-resident operand streams, independent of tile shape, ring depth and row stride.
+// The only lever is bytes staged per flop.  Every channel count of the U-Net is a multiple of 320, so:
+//   * tile 256 x 320 x 64: (256+320)*128 B = 72 KB per 10.5 MFLOP = 7.0 B/kFLOP  (gen 2: 256x160 -> 10.2, 128x256 -> 11.7);
+//   * 8 wave64 as 4(M) x 2(N), wave tile 64 x 160 = 160 accumulator VGPRs; the 256-VGPR budget leaves no room for
+//     double-buffered fragments of a whole half-step, so the W fragments STREAM through a 4-deep register ring (read two
+//     steps ahead of the 4 MFMAs that consume them) and the A fragments of the next k-half are read during the current one;
+//   * two LDS stages of 72 KB (double buffer): the DMA of K-tile v+1 is issued one piece per step over the first 9 of the 20
+//     steps of K-tile v, right after the barrier that freed its slot; one barrier per K-tile, placed after the LAST fragment
+//     read of the tile (step 17 of 20) so that steps 18-19 already prefetch the next tile's first fragments;
+//   * persistent workgroups, XCD-chunked tile order, fused epilogue (bias / row-bias / SiLU / GEGLU / 2 residuals) through a
+//     wave-private fp32 LDS patch in two 80-column passes, as in generation 2.
+// Same argument block and A addressing modes (dense / conv3x3 / temporal 3-tap, dual source, zero page) as gen 1/2.
+// Requires N % 320 == 0 (the dispatcher falls back to generation 2 otherwise).
+#include "gemm_common.h"
+#include <type_traits>
+
+namespace {
+
+#define EW3_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
+#define EW3_FENCE() asm volatile("" ::: "memory")
+#define EW3_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+constexpr int BM = 256, BN = 320, BK = 64, NW = 8, WAVES_N = 2;
+constexpr int WM = 64, WN = 160, FM = 4, FN = 10;
+constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW, NP = GA + GB;        // 4 + 5 DMA pieces per wave per K-tile
+constexpr int NSTEP = 2 * FN;                                          // 20 steps (k-half, W fragment) per K-tile
+constexpr int BAR_STEP = NSTEP - 3;                                    // barrier after the MFMAs of step 17
+
+template <int MODE, int EPI>
+__global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+
+    // ---- tile sequence of this persistent block: step i -> tile id i*G + (b%8)*(G/8) + b/8  (XCD-contiguous chunks)
+    const int G = gridDim.x;
+    const int total_tiles = p.tiles_m * p.tiles_n;
+    const int seq0 = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int n_my = seq0 < total_tiles ? (total_tiles - 1 - seq0) / G + 1 : 0;
+    const int nk = p.K / BK;
+    const int V = n_my * nk;                                           // K-tile stream length of this block
+    if (V == 0) return;
+
+    const int srow = lane >> 3;
+    const int slot = (lane & 7) ^ srow;
+
+    // ---------------- loader state (one K-tile ahead of the MFMA stream, across output tiles) ----------------
+    constexpr int NTAP = MODE == EW_A_CONV3X3 ? 9 : (MODE == EW_A_CONVT3 ? 3 : 1);
+    int ld_i = 0, ld_kt = 0, ld_tap = 0, ld_cc = 0;
+    int a_ctr[GA];                         // centre-tap pixel (row) index in the source tensors
+    int a_mask[GA];                        // bits 0..8 tap validity, bits 16..27 upsample (dy,dx) codes
+    const f16* b_ptr0 = p.w;               // W row of this lane's first piece (+ its 16-byte slot); piece j adds j*NW*8 rows
+
+    auto loader_new_tile = [&]() __attribute__((always_inline)) {
+        const int id = ld_i * G + seq0;
+        const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
+        const int m0 = tm * BM, n0 = tn * BN;
+#pragma unroll
+        for (int i = 0; i < GA; ++i) {
+            int m = m0 + (wave + NW * i) * 8 + srow;
+            m = m < p.M ? m : p.M - 1;
+            int ctr, mask = 1, dcode = 0;
+            if constexpr (MODE == EW_A_CONV3X3) {
+                const int hw = p.h_out * p.w_out;
+                const int img = m / hw, rem = m - img * hw;
+                const int oy = rem / p.w_out, ox = rem - oy * p.w_out;
+                const int hlim = p.upsample ? 2 * p.h_in : p.h_in, wlim = p.upsample ? 2 * p.w_in : p.w_in;
+                const int cy = oy * p.stride, cx = ox * p.stride;               // centre tap, in (possibly upsampled) input coords
+                mask = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
+                    if (iy >= 0 && iy < hlim && ix >= 0 && ix < wlim) mask |= 1 << t;
+                }
+                if (p.upsample) {
+                    const int sy = cy >> 1, sx = cx >> 1;                        // source pixel of the centre tap
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        dcode |= ((((cy + k - 1) >> 1) - sy) + 1) << (2 * k);        // dy(ky) in {-1,0,1} -> 2 bits
+                        dcode |= ((((cx + k - 1) >> 1) - sx) + 1) << (6 + 2 * k);    // dx(kx)
+                    }
+                    ctr = (img * p.h_in + sy) * p.w_in + sx;
+                } else {
+                    ctr = (img * p.h_in + cy) * p.w_in + cx;
+                }
+            } else if constexpr (MODE == EW_A_CONVT3) {
+                const int tp = p.tT * p.tP;
+                const int bb = m / tp, rem = m - bb * tp;
+                const int t = rem / p.tP, x = rem - t * p.tP;
+                mask = (t > 0 ? 1 : 0) | 2 | (t + 1 < p.tT ? 4 : 0);
+                ctr = (bb * p.tT + t) * p.tP + x;
+            } else {
+                ctr = m;
+            }
+            a_mask[i] = mask | (dcode << 16);
+            a_ctr[i] = ctr;
+        }
+        b_ptr0 = p.w + (size_t)(n0 + wave * 8 + srow) * p.K + slot * 8;          // N % 320 == 0: every W row exists
+        ld_kt = 0; ld_tap = 0; ld_cc = 0;
+    };
+
+    // staging of one K-tile = stage_begin (wave-uniform source selection, advances the stream counters) + NP DMA pieces
+    const f16* st_base = p.a;
+    const f16* st_zp = p.zero_page + slot * 8;
+    long long st_dl = 0;
+    int st_tap = 0, st_ld = 0, st_ch = 0;
+    size_t st_koff = 0;
+    char* st_buf = smem;
+    auto stage_begin = [&](char* buf) __attribute__((always_inline)) {
+        if (ld_kt == 0) loader_new_tile();
+        st_buf = buf;
+        st_tap = ld_tap;
+        const int cc = ld_cc;
+        const bool second = cc >= p.c1;
+        st_base = second ? p.a2 : p.a;
+        st_ld = second ? p.lda2 : p.lda;
+        st_ch = second ? cc - p.c1 : cc;
+        int dpix = 0;                                                       // wave-uniform tap delta in pixels
+        if constexpr (MODE == EW_A_CONV3X3) dpix = (st_tap / 3 - 1) * p.w_in + (st_tap % 3 - 1);
+        else if constexpr (MODE == EW_A_CONVT3) dpix = (st_tap - 1) * p.tP;
+        st_dl = (long long)dpix * st_ld + st_ch;
+        st_koff = (size_t)ld_kt * BK;
+        // K order: channel-chunk major, tap minor (the taps of a 64-channel chunk re-hit the same lines in L2 / TCP)
+        if (++ld_tap == NTAP) { ld_tap = 0; ld_cc += BK; }
+        if (++ld_kt == nk) { ld_kt = 0; ++ld_i; }
+    };
+    auto stage_piece = [&](int k) __attribute__((always_inline)) {     // k is a compile-time constant after unrolling
+        if (k < GA) {
+            const int i = k;
+            const f16* src = st_base + ((long long)a_ctr[i] * st_ld + (st_dl + slot * 8));
+            if constexpr (MODE == EW_A_CONV3X3) {
+                if (p.upsample) {                                           // per-row deltas (nearest-x2 source coordinates)
+                    const int dc = a_mask[i] >> 16;
+                    const int dy = ((dc >> (2 * (st_tap / 3))) & 3) - 1, dx = ((dc >> (6 + 2 * (st_tap % 3))) & 3) - 1;
+                    src = st_base + ((long long)(a_ctr[i] + dy * p.w_in + dx) * st_ld + (st_ch + slot * 8));
+                }
+            }
+            if constexpr (MODE != EW_A_DENSE) src = ((a_mask[i] >> st_tap) & 1) ? src : st_zp;
+            glds16(src, st_buf + (wave + NW * i) * 1024);
+        } else {
+            const int j = k - GA;
+            glds16(b_ptr0 + (size_t)(j * NW * 8) * p.K + st_koff, st_buf + A_BYTES + (wave + NW * j) * 1024);
+        }
+    };
+
+    // ---------------- fragment geometry ----------------
+    const int frow = lane & 15, fks = lane >> 4, sw = frow & 7;
+    int a_rd[2], b_rd[2];                  // per-lane byte offset inside a stage of A fragment 0 / W fragment 0, per k-half
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        const int so = ((kh * 4 + fks) ^ sw) << 4;
+        a_rd[kh] = (wm * WM + frow) * 128 + so;
+        b_rd[kh] = A_BYTES + (wn * WN + frow) * 128 + so;
+    }
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f16x8 af[2][FM];                       // A fragments of the two k-halves
+    f16x8 bfr[4];                          // W fragment ring: step t consumes bfr[t & 3]
+
+    // ---------------- prologue ----------------
+    stage_begin(smem);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) stage_piece(k);
+    int staged = 1;
+    EW3_WAIT_VM0();
+    EW3_FENCE();
+    __builtin_amdgcn_s_barrier();
+    EW3_FENCE();
+#pragma unroll
+    for (int i = 0; i < FM; ++i) af[0][i] = *(const f16x8*)(smem + a_rd[0] + i * 2048);
+    bfr[0] = *(const f16x8*)(smem + b_rd[0]);
+    bfr[1] = *(const f16x8*)(smem + b_rd[0] + 2048);
+
+    int cur_i = 0, cur_kt = 0;
+    int s_cur = 0;                                   // ring slot of stream position v
+    for (int v = 0; v < V; ++v) {
+        const char* cur = smem + s_cur * STAGE;
+        char* nxt = smem + (s_cur ^ 1) * STAGE;
+        const bool pend = staged < V;                // K-tile v+1 exists: stage it into the other slot during steps 0..8
+        if (pend) { stage_begin(nxt); ++staged; }
+#pragma unroll
+        for (int t = 0; t < NSTEP; ++t) {
+            const int kh = t / FN, j = t - kh * FN;
+            // ---- reads: W fragment of step t+2 (from the next K-tile once past the barrier), A fragments of the next k-half
+            if (t + 2 < NSTEP) {
+                const int kh2 = (t + 2) / FN, j2 = (t + 2) - kh2 * FN;
+                bfr[(t + 2) & 3] = *(const f16x8*)(cur + b_rd[kh2] + j2 * 2048);
+            } else {
+                bfr[(t + 2) & 3] = *(const f16x8*)(nxt + b_rd[0] + (t + 2 - NSTEP) * 2048);
+            }
+            if (t < FM) af[1][t] = *(const f16x8*)(cur + a_rd[1] + t * 2048);
+            if (t >= NSTEP - 2) {
+                const int i0 = (t - (NSTEP - 2)) * 2;
+                af[0][i0] = *(const f16x8*)(nxt + a_rd[0] + i0 * 2048);
+                af[0][i0 + 1] = *(const f16x8*)(nxt + a_rd[0] + (i0 + 1) * 2048);
+            }
+            if (t < NP) {
+                if (pend) stage_piece(t);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[t & 3], af[kh][i], acc[i][j], 0, 0, 0);   // D[n][m]
+            __builtin_amdgcn_sched_barrier(0);
+            if (t == BAR_STEP) {
+                // every fragment read of K-tile v has been issued; publish K-tile v+1 and free this slot.  Unconditional
+                // (also on the last position, where the prefetched fragments are stale and never used).
+                EW3_WAIT_VM0();
+                EW3_WAIT_LGKM0();
+                EW3_FENCE();
+                __builtin_amdgcn_s_barrier();
+                EW3_FENCE();
+            }
+        }
+        s_cur ^= 1;
+        if (++cur_kt == nk) {
+            // ------------------------- epilogue of output tile cur_i -------------------------
+            cur_kt = 0;
+            const int id = cur_i * G + seq0;
+            ++cur_i;
+            const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
+            const bool full = (tm * BM + wm * WM + WM <= p.M);          // N is always full (N % 320 == 0)
+            // wave-private fp32 patch in the slot just consumed (free since the barrier of step 17; the DMA of the next
+            // K-tile into it is issued by the NEXT position, after the closing barrier below)
+            constexpr int CP = 80;                                 // columns per pass
+            constexpr int LDP = CP + 4;                            // patch row stride (floats)
+            float* patch = (float*)(smem + (s_cur ^ 1) * STAGE) + wave * (16 * LDP);
+            const int m_w0 = tm * BM + wm * WM, n_w0 = tn * BN + wn * WN;
+            auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                const f16* bp = p.bias ? p.bias : p.zero_page;
+                const f16* rbp = p.rowbias ? p.rowbias : p.zero_page;
+                const f16* r1p = p.r1 ? p.r1 : p.zero_page;
+                const f16* r2p = p.r2 ? p.r2 : p.zero_page;
+                const int mbias = p.bias ? 1 : 0, mrb = p.rowbias ? 1 : 0, m1 = p.r1 ? 1 : 0, m2 = p.r2 ? 1 : 0;
+                const int ldrb = p.rowbias ? p.ld_rowbias : 0, ld1 = p.r1 ? p.ld_r1 : 0, ld2 = p.r2 ? p.ld_r2 : 0;
+                constexpr int VPR = CP / 8;                 // 16-byte output vectors per row and pass
+                constexpr int ITERS = (16 * VPR + 63) / 64;  // 3 (the last one partial: 160 = 2*64 + 32)
+                auto is_live = [&](int it) { return it * 64 + lane < 16 * VPR; };
+                if constexpr ((EPI & 8) == 0) {
+                    constexpr bool RB = EPI & 1, R1 = EPI & 2, R2 = EPI & 4;
+                    constexpr int NH = WN / CP;              // 2 column passes
+                    int rowv[ITERS], c8v[ITERS];
+#pragma unroll
+                    for (int it = 0; it < ITERS; ++it) {
+                        const int idx = it * 64 + lane;
+                        rowv[it] = is_live(it) ? idx / VPR : 0;
+                        c8v[it] = is_live(it) ? (idx - rowv[it] * VPR) * 8 : 0;
+                    }
+                    // vmcnt is in-order: the row operands of store step s+1 are requested BEFORE the store of step s
+                    f16x8 bvv[2], rbv[2], q1v[2], q2v[2];
+                    auto fetch = [&](int i, int h, int it, int set) {
+                        const int m = m_w0 + i * 16 + rowv[it], n = n_w0 + h * CP + c8v[it];
+                        const int mc = FULL ? m : min(m, p.M - 1);
+                        bvv[set] = *(const f16x8*)(bp + n * mbias);
+                        if constexpr (RB) rbv[set] = *(const f16x8*)(rbp + (size_t)(mc / p.rows_per_group) * ldrb + n * mrb);
+                        if constexpr (R1) q1v[set] = *(const f16x8*)(r1p + (size_t)mc * ld1 + n * m1);
+                        if constexpr (R2) q2v[set] = *(const f16x8*)(r2p + (size_t)mc * ld2 + n * m2);
+                    };
+                    fetch(0, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) {
+#pragma unroll
+                            for (int jj = 0; jj < CP / 16; ++jj) {
+                                *(f32x4*)(patch + frow * LDP + jj * 16 + fks * 4) = acc[i][h * (CP / 16) + jj];
+                                acc[i][h * (CP / 16) + jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            }
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int it = 0; it < ITERS; ++it) {
+                                const int sidx = (i * NH + h) * ITERS + it, set = sidx & 1;
+                                if (it + 1 < ITERS) fetch(i, h, it + 1, set ^ 1);
+                                else if (h + 1 < NH) fetch(i, h + 1, 0, set ^ 1);
+                                else if (i + 1 < FM) fetch(i + 1, 0, 0, set ^ 1);
+                                const int row = rowv[it], c8 = c8v[it];
+                                const int m = m_w0 + i * 16 + row, n = n_w0 + h * CP + c8;
+                                const f32x4 lo = *(const f32x4*)(patch + row * LDP + c8);
+                                const f32x4 hi = *(const f32x4*)(patch + row * LDP + c8 + 4);
+                                const float vv[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                                f16x8 o;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    float x = vv[e] + (float)bvv[set][e];
+                                    if constexpr (RB) x += (float)rbv[set][e];
+                                    if (p.act == EW_ACT_SILU) x = ew_silu(x);
+                                    x *= p.c_acc;
+                                    if constexpr (R1) x += p.c_r1 * (float)q1v[set][e];
+                                    if constexpr (R2) x += p.c_r2 * (float)q2v[set][e];
+                                    o[e] = (f16)x;
+                                }
+                                if (is_live(it) && (FULL || m < p.M) && !(p.dbg & 1)) *(f16x8*)(p.out + (size_t)m * p.ld_out + n) = o;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                } else {
+                    // GEGLU: staged column blocks of 32 = [16 value | 16 gate] -> fragment 2q holds the values, 2q+1 the gates of
+                    // the SAME (row, column) positions in the SAME lane: value*gelu(gate) in registers, WN/2 = 80 output columns
+                    f32x4 bq[FN];
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        const f16x4 b4 = *(const f16x4*)(bp + (n_w0 + j * 16 + fks * 4) * mbias);
+                        bq[j] = (f32x4){(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
+                    }
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                        for (int q = 0; q < FN / 2; ++q) {
+                            const f32x4 va = acc[i][2 * q] + bq[2 * q], gg = acc[i][2 * q + 1] + bq[2 * q + 1];
+                            f32x4 o4;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o4[e] = va[e] * ew_gelu(gg[e]);
+                            *(f32x4*)(patch + frow * LDP + q * 16 + fks * 4) = o4;
+                            acc[i][2 * q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            acc[i][2 * q + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        }
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int it = 0; it < ITERS; ++it) {
+                            const int idx = it * 64 + lane;
+                            const int row = is_live(it) ? idx / VPR : 0, c8 = is_live(it) ? (idx - row * VPR) * 8 : 0;
+                            const int m = m_w0 + i * 16 + row;
+                            const f32x4 lo = *(const f32x4*)(patch + row * LDP + c8), hi = *(const f32x4*)(patch + row * LDP + c8 + 4);
+                            const f16x8 o = {(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
+                            const int no = (n_w0 >> 1) + c8;
+                            if (is_live(it) && (FULL || m < p.M) && !(p.dbg & 1)) *(f16x8*)(p.out + (size_t)m * p.ld_out + no) = o;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            };
+            if (p.dbg & 2) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) { asm volatile("" :: "v"(acc[i][j])); acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            } else {
+                if (full) epilogue(std::true_type{}); else epilogue(std::false_type{});
+                // the patch lives in the slot the next position's DMA will overwrite
+                EW3_WAIT_LGKM0();
+                EW3_FENCE();
+                __builtin_amdgcn_s_barrier();
+                EW3_FENCE();
+            }
+        }
+    }
+}
+
+template <int MODE, int EPI>
+ew_status launch3(const GemmP& p, hipStream_t s) {
+    GemmP q = p;
+    q.tiles_m = ew_cdiv(p.M, BM);
+    q.tiles_n = p.N / BN;
+    const size_t lds = 2 * STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<MODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { ew_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return EW_ERR_HIP; }
+        attr_set = true;
+    }
+    const long long tiles = (long long)q.tiles_m * q.tiles_n;
+    int grid = 256;                                   // persistent: one 8-wave workgroup per CU
+    if (tiles < grid) grid = (int)((tiles + 7) / 8 * 8);
+    hipLaunchKernelGGL((gemm3_kernel<MODE, EPI>), dim3(grid), dim3(64 * NW), lds, s, q);
+    return ew_check_launch("ew_gemm_f16(gen3)");
+}
+
+// operand sets that occur in the U-Net (evoworld_amd/unet.py); any other mask runs on the smallest compiled superset
+template <int MODE>
+ew_status dispatch_epi3(const GemmP& p, hipStream_t s) {
+    if (p.act == EW_ACT_GEGLU) {
+        if constexpr (MODE == EW_A_DENSE) return launch3<MODE, 8>(p, s);
+        else { ew_set_error("ew_gemm_f16: GEGLU epilogue is only built for dense mode"); return EW_ERR_UNSUPPORTED; }
+    }
+    const int mask = (p.rowbias ? 1 : 0) | (p.r1 ? 2 : 0) | (p.r2 ? 4 : 0);
+    if (mask == 0) return launch3<MODE, 0>(p, s);
+    if (mask == 1) return launch3<MODE, 1>(p, s);
+    if (mask == 2) return launch3<MODE, 2>(p, s);
+    if constexpr (MODE == EW_A_DENSE) {
+        if (mask == 3) return launch3<MODE, 3>(p, s);
+        if (mask == 6 || mask == 4) return launch3<MODE, 6>(p, s);
+    }
+    return launch3<MODE, 7>(p, s);
+}
+
+}  // namespace
+
+// true when generation 3 can run the problem AND is expected to be the faster choice (enough 256x320 tiles to fill the chip)
+bool ew_gemm3_wants(const GemmP& p) {
+    if (p.N % BN != 0) return false;
+    const long long tiles = (long long)ew_cdiv(p.M, BM) * (p.N / BN);
+    return tiles >= 200;
+}
+
+ew_status ew_gemm3_dispatch(const GemmP& p, hipStream_t s) {
+    if (p.mode == EW_A_CONV3X3) return dispatch_epi3<EW_A_CONV3X3>(p, s);
+    if (p.mode == EW_A_CONVT3) return dispatch_epi3<EW_A_CONVT3>(p, s);
+    return dispatch_epi3<EW_A_DENSE>(p, s);
+}

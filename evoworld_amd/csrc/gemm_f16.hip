@@ -264,6 +264,8 @@ ew_status launch(const GemmP& p, hipStream_t s) {
 }  // namespace
 
 ew_status ew_gemm2_dispatch(const GemmP& p, hipStream_t s);   // gemm2_f16.hip
+ew_status ew_gemm3_dispatch(const GemmP& p, hipStream_t s);   // gemm3_f16.hip
+bool ew_gemm3_wants(const GemmP& p);
 static int g_gemm_gen = -1;
 static int g_gemm_dbg = 0;
 extern "C" void ew_set_gemm_debug(int d) { g_gemm_dbg = d; }
@@ -271,7 +273,7 @@ extern "C" void ew_set_gemm_generation(int gen) { g_gemm_gen = gen; }
 extern "C" int ew_get_gemm_generation(void) {
     if (g_gemm_gen < 0) {
         const char* e = getenv("EW_GEMM_GEN");
-        g_gemm_gen = e ? atoi(e) : 2;
+        g_gemm_gen = e ? atoi(e) : 3;
     }
     return g_gemm_gen;
 }
@@ -319,7 +321,9 @@ extern "C" ew_status ew_gemm_f16(const ew_gemm_args* a, void* stream) {
     p.tiles_m = p.tiles_n = 0;
     p.dbg = g_gemm_dbg;
     hipStream_t s = (hipStream_t)stream;
-    if (ew_get_gemm_generation() == 2) return ew_gemm2_dispatch(p, s);
+    // generation 3 (256x320 tile) where it applies and fills the chip, generation 2 otherwise
+    if (ew_get_gemm_generation() >= 3 && ew_gemm3_wants(p)) return ew_gemm3_dispatch(p, s);
+    if (ew_get_gemm_generation() >= 2) return ew_gemm2_dispatch(p, s);
     // generation 1 tile choice: every channel count of the U-Net is a multiple of 160 (320*k); GEGLU and odd sizes use 128
     if (a->act != EW_ACT_GEGLU && a->N % 160 == 0) return launch<128, 160>(p, s);
     return launch<128, 128>(p, s);

@@ -28,6 +28,8 @@ def cases():
     B.gemm_case("L1 ff_down_res", 115200, 640, 2560, res=True)
     B.gemm_case("L2 ff_down_res", 28800, 1280, 5120, res=True)
     B.gemm_case("L0 proj_res", 460800, 320, 320, res=True)
+    B.gemm_case("L1 proj_res", 115200, 640, 640, res=True)
+    B.gemm_case("L1 qkv", 115200, 1920, 640)
     B.gemm_case("L0 qkv", 460800, 960, 320)
     B.conv_case("L0 320", 50, 320, 320, 72, 128)
     B.conv_case("L0 cat640", 50, 320, 320, 72, 128, c2=320)
