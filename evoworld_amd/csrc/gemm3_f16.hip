@@ -62,9 +62,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
         const int id = ld_i * G + seq0;
         const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
         const int m0 = tm * BM, n0 = tn * BN;
+        // per-lane constants are re-derived from an opaque copy of the lane id: hoisted out of the K-tile stream they would
+        // be live across the main loop, where every VGPR is taken, and come back as scratch reloads (each with a vmcnt(0))
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int srow_o = lane_o >> 3, slot_o = (lane_o & 7) ^ srow_o;
 #pragma unroll
         for (int i = 0; i < GA; ++i) {
-            int m = m0 + (wave + NW * i) * 8 + srow;
+            int m = m0 + (wave + NW * i) * 8 + srow_o;
             m = m < p.M ? m : p.M - 1;
             int ctr, mask = 1, dcode = 0;
             if constexpr (MODE == EW_A_CONV3X3) {
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
             a_mask[i] = mask | (dcode << 16);
             a_ctr[i] = ctr;
         }
-        b_ptr0 = p.w + (size_t)(n0 + wave * 8 + srow) * p.K + slot * 8;          // N % 320 == 0: every W row exists
+        b_ptr0 = p.w + (size_t)(n0 + wave * 8 + srow_o) * p.K + slot_o * 8;          // N % 320 == 0: every W row exists
         ld_kt = 0; ld_tap = 0; ld_cc = 0;
     };
 
@@ -187,6 +192,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
     for (int v = 0; v < V; ++v) {
         const char* cur = smem + s_cur * STAGE;
         char* nxt = smem + (s_cur ^ 1) * STAGE;
+        const bool tile_end = cur_kt == nk - 1;
         const bool pend = staged < V;                // K-tile v+1 exists: stage it into the other slot during steps 0..8
         if (pend) { stage_begin(nxt); ++staged; }
 #pragma unroll
@@ -196,14 +202,17 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
             if (t + 2 < NSTEP) {
                 const int kh2 = (t + 2) / FN, j2 = (t + 2) - kh2 * FN;
                 bfr[(t + 2) & 3] = *(const f16x8*)(cur + b_rd[kh2] + j2 * 2048);
-            } else {
-                bfr[(t + 2) & 3] = *(const f16x8*)(nxt + b_rd[0] + (t + 2 - NSTEP) * 2048);
             }
             if (t < FM) af[1][t] = *(const f16x8*)(cur + a_rd[1] + t * 2048);
             if (t >= NSTEP - 2) {
-                const int i0 = (t - (NSTEP - 2)) * 2;
-                af[0][i0] = *(const f16x8*)(nxt + a_rd[0] + i0 * 2048);
-                af[0][i0 + 1] = *(const f16x8*)(nxt + a_rd[0] + (i0 + 1) * 2048);
+                // first fragments of the next K-tile -- except at a tile end: the epilogue needs the registers (160 live
+                // accumulators), so they are read after it instead
+                if (!tile_end) {
+                    const int i0 = (t - (NSTEP - 2)) * 2;
+                    bfr[(t + 2) & 3] = *(const f16x8*)(nxt + b_rd[0] + (t + 2 - NSTEP) * 2048);
+                    af[0][i0] = *(const f16x8*)(nxt + a_rd[0] + i0 * 2048);
+                    af[0][i0 + 1] = *(const f16x8*)(nxt + a_rd[0] + (i0 + 1) * 2048);
+                }
             }
             if (t < NP) {
                 if (pend) stage_piece(t);
@@ -239,6 +248,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
             const int m_w0 = tm * BM + wm * WM, n_w0 = tn * BN + wn * WN;
             auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
                 constexpr bool FULL = decltype(full_tag)::value;
+                int lane = tid & 63;                        // opaque copy: keeps the epilogue's per-lane constants out of the main loop
+                asm volatile("" : "+v"(lane));
+                const int frow = lane & 15, fks = lane >> 4;
                 const f16* bp = p.bias ? p.bias : p.zero_page;
                 const f16* rbp = p.rowbias ? p.rowbias : p.zero_page;
                 const f16* r1p = p.r1 ? p.r1 : p.zero_page;
@@ -258,17 +270,28 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                         rowv[it] = is_live(it) ? idx / VPR : 0;
                         c8v[it] = is_live(it) ? (idx - rowv[it] * VPR) * 8 : 0;
                     }
-                    // vmcnt is in-order: the row operands of store step s+1 are requested BEFORE the store of step s
-                    f16x8 bvv[2], rbv[2], q1v[2], q2v[2];
-                    auto fetch = [&](int i, int h, int it, int set) {
+                    // vmcnt is in-order: a load issued after a store cannot be waited for without draining that store, so the
+                    // operands of store step s+1 are requested BEFORE the store of step s -- but AFTER step s has consumed
+                    // its own operands, into the same registers (one operand set: the 160 live accumulators leave no room
+                    // for two).
+                    f16x8 bvv, rbv, q1v, q2v;
+                    // row-bias group of a row: one boundary at most inside the wave's 64 rows when rows_per_group >= 64
+                    const int rpg = p.rows_per_group;
+                    const int g0 = m_w0 / rpg;
+                    const int gbound = rpg >= WM ? (g0 + 1) * rpg : 0x7fffffff;
+                    auto fetch = [&](int i, int h, int it) {
                         const int m = m_w0 + i * 16 + rowv[it], n = n_w0 + h * CP + c8v[it];
                         const int mc = FULL ? m : min(m, p.M - 1);
-                        bvv[set] = *(const f16x8*)(bp + n * mbias);
-                        if constexpr (RB) rbv[set] = *(const f16x8*)(rbp + (size_t)(mc / p.rows_per_group) * ldrb + n * mrb);
-                        if constexpr (R1) q1v[set] = *(const f16x8*)(r1p + (size_t)mc * ld1 + n * m1);
-                        if constexpr (R2) q2v[set] = *(const f16x8*)(r2p + (size_t)mc * ld2 + n * m2);
+                        // uniform base + 32-bit byte offset (every operand of this path is < 4 GB): one VGPR per address
+                        bvv = *(const f16x8*)((const char*)bp + (unsigned)(n * mbias) * 2u);
+                        if constexpr (RB) {
+                            const int g = rpg >= WM ? g0 + (mc >= gbound ? 1 : 0) : mc / rpg;
+                            rbv = *(const f16x8*)((const char*)rbp + (unsigned)(g * ldrb + n * mrb) * 2u);
+                        }
+                        if constexpr (R1) q1v = *(const f16x8*)((const char*)r1p + (unsigned)(mc * ld1 + n * m1) * 2u);
+                        if constexpr (R2) q2v = *(const f16x8*)((const char*)r2p + (unsigned)(mc * ld2 + n * m2) * 2u);
                     };
-                    fetch(0, 0, 0, 0);
+                    fetch(0, 0, 0);
 #pragma unroll
                     for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -281,27 +304,34 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                             __builtin_amdgcn_wave_barrier();
 #pragma unroll
                             for (int it = 0; it < ITERS; ++it) {
-                                const int sidx = (i * NH + h) * ITERS + it, set = sidx & 1;
-                                if (it + 1 < ITERS) fetch(i, h, it + 1, set ^ 1);
-                                else if (h + 1 < NH) fetch(i, h + 1, 0, set ^ 1);
-                                else if (i + 1 < FM) fetch(i + 1, 0, 0, set ^ 1);
                                 const int row = rowv[it], c8 = c8v[it];
                                 const int m = m_w0 + i * 16 + row, n = n_w0 + h * CP + c8;
                                 const f32x4 lo = *(const f32x4*)(patch + row * LDP + c8);
                                 const f32x4 hi = *(const f32x4*)(patch + row * LDP + c8 + 4);
-                                const float vv[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                                float vv[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                                 f16x8 o;
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) {
-                                    float x = vv[e] + (float)bvv[set][e];
-                                    if constexpr (RB) x += (float)rbv[set][e];
-                                    if (p.act == EW_ACT_SILU) x = ew_silu(x);
-                                    x *= p.c_acc;
-                                    if constexpr (R1) x += p.c_r1 * (float)q1v[set][e];
-                                    if constexpr (R2) x += p.c_r2 * (float)q2v[set][e];
+                                    vv[e] += (float)bvv[e];
+                                    if constexpr (RB) vv[e] += (float)rbv[e];
+                                }
+                                if (p.act == EW_ACT_SILU) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) vv[e] = ew_silu(vv[e]);
+                                }
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    float x = vv[e] * p.c_acc;
+                                    if constexpr (R1) x += p.c_r1 * (float)q1v[e];
+                                    if constexpr (R2) x += p.c_r2 * (float)q2v[e];
                                     o[e] = (f16)x;
                                 }
-                                if (is_live(it) && (FULL || m < p.M) && !(p.dbg & 1)) *(f16x8*)(p.out + (size_t)m * p.ld_out + n) = o;
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (it + 1 < ITERS) fetch(i, h, it + 1);
+                                else if (h + 1 < NH) fetch(i, h + 1, 0);
+                                else if (i + 1 < FM) fetch(i + 1, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (is_live(it) && (FULL || m < p.M) && !(p.dbg & 1)) *(f16x8*)((char*)p.out + (unsigned)(m * p.ld_out + n) * 2u) = o;
                             }
                             __builtin_amdgcn_wave_barrier();
                         }
@@ -355,6 +385,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                 __builtin_amdgcn_s_barrier();
                 EW3_FENCE();
             }
+            // first fragments of the next tile's first K-tile (skipped at steps 18-19 of this position)
+            {
+                const char* c2 = smem + s_cur * STAGE;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) af[0][i] = *(const f16x8*)(c2 + a_rd[0] + i * 2048);
+                bfr[0] = *(const f16x8*)(c2 + b_rd[0]);
+                bfr[1] = *(const f16x8*)(c2 + b_rd[0] + 2048);
+            }
         }
     }
 }
@@ -400,7 +438,13 @@ ew_status dispatch_epi3(const GemmP& p, hipStream_t s) {
 
 // true when generation 3 can run the problem AND is expected to be the faster choice (enough 256x320 tiles to fill the chip)
 bool ew_gemm3_wants(const GemmP& p) {
-    if (p.N % BN != 0) return false;
+    if (p.N % BN != 0 || p.M < 4 * BM) return false;
+    // the epilogue addresses its row operands as uniform base + 32-bit byte offset
+    const long long ld_max = max(max((long long)p.ld_out, (long long)p.ld_r1), max((long long)p.ld_r2, (long long)p.ld_rowbias));
+    if ((long long)p.M * ld_max * 2 >= (1LL << 32)) return false;
+    // one tile column and a short K: 1800 tiles = 7.03 rounds over 256 CUs cost 8, and the residual-carrying epilogue is
+    // store-bound anyway -- generation 2's 256x160 tiles (14.06 -> 15 rounds) measured 5-10 % faster there
+    if (p.mode == EW_A_DENSE && p.N == BN && p.K <= 1280 && (p.r1 || p.r2)) return false;
     const long long tiles = (long long)ew_cdiv(p.M, BM) * (p.N / BN);
     return tiles >= 200;
 }

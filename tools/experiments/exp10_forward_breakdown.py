@@ -78,23 +78,26 @@ def run(dbg):
 
 
 try:
-    sig = open(os.path.join(os.path.dirname(_lib.__file__), "unet.py")).read()
-    tot0, a0 = run(0)
-    tot2, a2 = run(2)
-    tot0b, a0b = run(0)
-    print(f"forward (with per-call events): {tot0:.1f} ms / {tot0b:.1f} ms; with GEMM epilogues skipped: {tot2:.1f} ms")
-    rows = sorted(a0.items(), key=lambda kv: -kv[1][1])
-    print(f"{'call site':78s} {'n':>4s} {'ms':>8s} {'ms(b)':>8s} {'no-epi':>8s} {'TF/s':>7s} {'TF/s no-epi':>11s}")
-    sg = sn = 0.0
+    lib.ew_set_gemm_generation.argtypes = [ctypes.c_int]
+    lib.ew_set_gemm_generation(2)
+    tot2, a2 = run(0)
+    lib.ew_set_gemm_generation(3)
+    tot3, a3 = run(0)
+    lib.ew_set_gemm_generation(2)
+    tot2b, a2b = run(0)
+    lib.ew_set_gemm_generation(3)
+    tot3b, a3b = run(0)
+    print(f"forward (with per-call events): gen2 {tot2:.1f} / {tot2b:.1f} ms   gen3 {tot3:.1f} / {tot3b:.1f} ms")
+    rows = sorted(a2.items(), key=lambda kv: -kv[1][1])
+    print(f"{'call site':78s} {'n':>4s} {'gen2 ms':>8s} {'gen3 ms':>8s} {'gain':>7s} {'TF/s g3':>8s}")
+    sg2 = sg3 = 0.0
     for key, (n, ms, fl) in rows:
-        msb = a0b[key][1]
-        ms2 = a2.get(key, [0, 0.0])[1]
-        tf = fl * n / min(ms, msb) / 1e9 if fl else 0
-        tf2 = fl * n / ms2 / 1e9 if fl and ms2 else 0
+        m2 = min(ms, a2b[key][1])
+        m3 = min(a3[key][1], a3b[key][1])
         if key.startswith("gemm"):
-            sg += min(ms, msb)
-            sn += ms2
-        print(f"{key:78s} {n:4d} {ms:8.2f} {msb:8.2f} {ms2:8.2f} {tf:7.0f} {tf2:11.0f}")
-    print(f"GEMM total {sg:.1f} ms, with epilogue skipped {sn:.1f} ms")
+            sg2 += m2
+            sg3 += m3
+        print(f"{key:78s} {n:4d} {m2:8.2f} {m3:8.2f} {100 * (m2 / m3 - 1):+6.1f}% {fl * n / m3 / 1e9 if fl else 0:8.0f}")
+    print(f"GEMM total gen2 {sg2:.1f} ms, gen3 {sg3:.1f} ms")
 finally:
     lib.ew_set_gemm_debug(0)
