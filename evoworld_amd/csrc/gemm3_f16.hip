@@ -23,13 +23,27 @@ namespace {
 #define EW3_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 #define EW3_FENCE() asm volatile("" ::: "memory")
 #define EW3_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#if defined(EW_G3_ABLATE) && (EW_G3_ABLATE & 2)
+#define EW3_LDS(ptr) (f16x8{})                       /* ablation: no ds_reads */
+#else
+#define EW3_LDS(ptr) (*(const f16x8*)(ptr))
+#endif
 
 constexpr int BM = 256, BN = 320, BK = 64, NW = 8, WAVES_N = 2;
 constexpr int WM = 64, WN = 160, FM = 4, FN = 10;
 constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
 constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW, NP = GA + GB;        // 4 + 5 DMA pieces per wave per K-tile
 constexpr int NSTEP = 2 * FN;                                          // 20 steps (k-half, W fragment) per K-tile
-constexpr int BAR_STEP = NSTEP - 3;                                    // barrier after the MFMAs of step 17
+#ifdef EW_G3_NOPIN
+#define EW3_PIN()
+#else
+#define EW3_PIN() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifndef EW_G3_DIST
+#define EW_G3_DIST 2
+#endif
+constexpr int PD = EW_G3_DIST;                                         // W fragments are read PD steps ahead of their MFMAs (ring of 4)
+constexpr int BAR_STEP = NSTEP - 1 - PD;                               // barrier after the step that issues the tile's last read
 
 template <int MODE, int EPI>
 __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
@@ -148,10 +162,16 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                 }
             }
             if constexpr (MODE != EW_A_DENSE) src = ((a_mask[i] >> st_tap) & 1) ? src : st_zp;
+#if defined(EW_G3_ABLATE) && (EW_G3_ABLATE & 4)
+            asm volatile("" ::"v"(src));                                                                         // ablation: no DMA
+#else
             glds16(src, st_buf + (wave + NW * i) * 1024);
+#endif
         } else {
             const int j = k - GA;
+#if !(defined(EW_G3_ABLATE) && (EW_G3_ABLATE & 4))
             glds16(b_ptr0 + (size_t)(j * NW * 8) * p.K + st_koff, st_buf + A_BYTES + (wave + NW * j) * 1024);
+#endif
         }
     };
 
@@ -183,9 +203,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
     __builtin_amdgcn_s_barrier();
     EW3_FENCE();
 #pragma unroll
-    for (int i = 0; i < FM; ++i) af[0][i] = *(const f16x8*)(smem + a_rd[0] + i * 2048);
-    bfr[0] = *(const f16x8*)(smem + b_rd[0]);
-    bfr[1] = *(const f16x8*)(smem + b_rd[0] + 2048);
+    for (int i = 0; i < FM; ++i) af[0][i] = EW3_LDS(smem + a_rd[0] + i * 2048);
+#pragma unroll
+    for (int j = 0; j < PD; ++j) bfr[j] = EW3_LDS(smem + b_rd[0] + j * 2048);
 
     int cur_i = 0, cur_kt = 0;
     int s_cur = 0;                                   // ring slot of stream position v
@@ -199,29 +219,35 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
         for (int t = 0; t < NSTEP; ++t) {
             const int kh = t / FN, j = t - kh * FN;
             // ---- reads: W fragment of step t+2 (from the next K-tile once past the barrier), A fragments of the next k-half
-            if (t + 2 < NSTEP) {
-                const int kh2 = (t + 2) / FN, j2 = (t + 2) - kh2 * FN;
-                bfr[(t + 2) & 3] = *(const f16x8*)(cur + b_rd[kh2] + j2 * 2048);
+            if (t + PD < NSTEP) {
+                const int kh2 = (t + PD) / FN, j2 = (t + PD) - kh2 * FN;
+                bfr[(t + PD) & 3] = EW3_LDS(cur + b_rd[kh2] + j2 * 2048);
             }
-            if (t < FM) af[1][t] = *(const f16x8*)(cur + a_rd[1] + t * 2048);
-            if (t >= NSTEP - 2) {
+            if (t < FM) af[1][t] = EW3_LDS(cur + a_rd[1] + t * 2048);
+            if (t >= NSTEP - PD) {
                 // first fragments of the next K-tile -- except at a tile end: the epilogue needs the registers (160 live
                 // accumulators), so they are read after it instead
                 if (!tile_end) {
-                    const int i0 = (t - (NSTEP - 2)) * 2;
-                    bfr[(t + 2) & 3] = *(const f16x8*)(nxt + b_rd[0] + (t + 2 - NSTEP) * 2048);
-                    af[0][i0] = *(const f16x8*)(nxt + a_rd[0] + i0 * 2048);
-                    af[0][i0 + 1] = *(const f16x8*)(nxt + a_rd[0] + (i0 + 1) * 2048);
+                    bfr[(t + PD) & 3] = EW3_LDS(nxt + b_rd[0] + (t + PD - NSTEP) * 2048);
+                    if (t >= NSTEP - 2) {
+                        const int i0 = (t - (NSTEP - 2)) * 2;
+                        af[0][i0] = EW3_LDS(nxt + a_rd[0] + i0 * 2048);
+                        af[0][i0 + 1] = EW3_LDS(nxt + a_rd[0] + (i0 + 1) * 2048);
+                    }
                 }
             }
             if (t < NP) {
                 if (pend) stage_piece(t);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            EW3_PIN();
 #pragma unroll
             for (int i = 0; i < FM; ++i)
+#if defined(EW_G3_ABLATE) && (EW_G3_ABLATE & 1)
+                asm volatile("" ::"v"(bfr[t & 3]), "v"(af[kh][i]));                                              // ablation: no MFMA
+#else
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[t & 3], af[kh][i], acc[i][j], 0, 0, 0);   // D[n][m]
-            __builtin_amdgcn_sched_barrier(0);
+#endif
+            EW3_PIN();
             if (t == BAR_STEP) {
                 // every fragment read of K-tile v has been issued; publish K-tile v+1 and free this slot.  Unconditional
                 // (also on the last position, where the prefetched fragments are stale and never used).
@@ -389,9 +415,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
             {
                 const char* c2 = smem + s_cur * STAGE;
 #pragma unroll
-                for (int i = 0; i < FM; ++i) af[0][i] = *(const f16x8*)(c2 + a_rd[0] + i * 2048);
-                bfr[0] = *(const f16x8*)(c2 + b_rd[0]);
-                bfr[1] = *(const f16x8*)(c2 + b_rd[0] + 2048);
+                for (int i = 0; i < FM; ++i) af[0][i] = EW3_LDS(c2 + a_rd[0] + i * 2048);
+#pragma unroll
+                for (int j = 0; j < PD; ++j) bfr[j] = EW3_LDS(c2 + b_rd[0] + j * 2048);
             }
         }
     }
