@@ -466,8 +466,9 @@ ew_status dispatch_epi3(const GemmP& p, hipStream_t s) {
 bool ew_gemm3_wants(const GemmP& p) {
     if (p.N % BN != 0 || p.M < 4 * BM) return false;
     // the epilogue addresses its row operands as uniform base + 32-bit byte offset
-    const long long ld_max = max(max((long long)p.ld_out, (long long)p.ld_r1), max((long long)p.ld_r2, (long long)p.ld_rowbias));
+    const long long ld_max = max((long long)p.ld_out, max((long long)p.ld_r1, (long long)p.ld_r2));
     if ((long long)p.M * ld_max * 2 >= (1LL << 32)) return false;
+    if (p.rowbias && ((long long)p.M / max(1, p.rows_per_group) + 2) * p.ld_rowbias * 2 >= (1LL << 32)) return false;
     // one tile column and a short K: 1800 tiles = 7.03 rounds over 256 CUs cost 8, and the residual-carrying epilogue is
     // store-bound anyway -- generation 2's 256x160 tiles (14.06 -> 15 rounds) measured 5-10 % faster there
     if (p.mode == EW_A_DENSE && p.N == BN && p.K <= 1280 && (p.r1 || p.r2)) return false;
