@@ -70,6 +70,70 @@ def cpu_baseline(max_threads=32):
                       "scaled x50 to B=2,T=25 and x25 denoise steps per clip"}
 
 
+def kernel_breakdown(unet, pipe, latents, image_latents, ehs, plucker, T, h, w, top=8):
+    """One extra (untimed) U-Net forward with a HIP-event pair around every C-ABI launch, grouped by the kernel the library
+    actually dispatched (names as rocprofv3 prints them, so the committed profiles/ summary can be compared line by line):
+    per kernel the launches per forward, the average duration, and for the MFMA kernels algorithmic flops / time against the
+    dense fp16 peak.  Event pairs add ~2 % to the chain; the headline numbers come from the untouched timed region above."""
+    import collections
+    import ctypes
+    from evoworld_amd import _lib
+    lib = _lib.load()
+    rec = []
+    names = ("ew_gemm_f16", "ew_groupnorm_stats_f16", "ew_groupnorm_apply_f16", "ew_layernorm_f16", "ew_attn_spatial_f16",
+             "ew_attn_temporal_f16")
+    kname = {"ew_groupnorm_stats_f16": "gn_stats_kernel", "ew_groupnorm_apply_f16": "gn_apply_kernel",
+             "ew_layernorm_f16": "ln_kernel", "ew_attn_spatial_f16": "attn_spatial_kernel", "ew_attn_temporal_f16": "attn_temporal_kernel"}
+    orig = {n: getattr(lib, n) for n in names}
+
+    def wrap(n):
+        fn = orig[n]
+
+        def timed(*a):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = fn(*a)
+            e.record()
+            fl = 0.0
+            if n == "ew_gemm_f16":
+                g = a[0]._obj
+                key = lib.ew_gemm_last_kernel().decode()
+                fl = 2.0 * g.M * g.N * (g.c1 + g.c2) * {0: 1, 1: 9, 2: 3}[g.mode]
+            else:
+                key = kname[n]
+                if n == "ew_attn_spatial_f16":
+                    fl = 4.0 * a[4] * a[6] * a[5] * a[5] * 64          # n_seq * heads * S^2 * head_dim
+            rec.append((key, fl, s, e))
+            return r
+        return timed
+    try:
+        for n in names:
+            setattr(lib, n, wrap(n))
+        x_in = torch.zeros(2 * T * h * w, 64, dtype=torch.float16, device=latents.device)
+        ids = torch.tensor([[6.0, 127.0, 0.02]] * 2, device=latents.device)
+        e2 = torch.cat([torch.zeros_like(ehs), ehs], 0).to(torch.float16)
+        unet.forward_nhwc(x_in, 1.0, e2, ids, 2, T, h, w)
+        torch.cuda.synchronize()
+    finally:
+        for n in names:
+            setattr(lib, n, orig[n])
+    agg = collections.OrderedDict()
+    for key, fl, s, e in rec:
+        t = agg.setdefault(key, [0, 0.0, 0.0])
+        t[0] += 1
+        t[1] += s.elapsed_time(e)
+        t[2] += fl
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]
+    out = []
+    for key, (n, ms, fl) in rows:
+        d = {"kernel": key, "launches_per_forward": n, "avg_us": round(ms / n * 1e3, 1), "total_ms": round(ms, 2)}
+        if fl:
+            d["achieved_tflops"] = round(fl / ms / 1e9, 1)
+            d["frac"] = round(fl / ms / 1e9 / PEAK_F16_DENSE_TFLOPS, 3)
+        out.append(d)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +203,8 @@ def main():
     unet.forward_nhwc = orig_forward
     finite = all(bool(torch.isfinite(r).all()) for r in res)
 
+    kernels = kernel_breakdown(unet, pipe, latents, image_latents, ehs, plucker, T, h, w) if rank == 0 else None
+
     if rank == 0:
         fw_ms = sum(s.elapsed_time(e) for s, e in fw_events) / max(1, len(fw_events))
         full = (not args.tiny) and (T, args.height, args.width, args.denoise_steps) == (25, 576, 1024, 25)
@@ -154,7 +220,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "U-Net denoise step (all launches of one forward, HIP events on the launch stream)",
                          "achieved": ach, "peak": PEAK_F16_DENSE_TFLOPS, "unit": "TFLOP/s",
                          "frac": (ach / PEAK_F16_DENSE_TFLOPS) if ach else None, "traffic": None,
-                         "algorithmic_tflop_per_launch": ALGO_TFLOP_PER_FORWARD},
+                         "algorithmic_tflop_per_launch": ALGO_TFLOP_PER_FORWARD,
+                         "kernels": kernels},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

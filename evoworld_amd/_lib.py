@@ -16,7 +16,7 @@ ABI_VERSION = 1
 
 # every symbol declared in include/evoworld_hip.h
 SYMBOLS = [
-    "ew_abi_version", "ew_last_error", "ew_gemm_f16", "ew_set_gemm_generation", "ew_get_gemm_generation", "ew_set_gemm_debug", "ew_groupnorm_stats_f16", "ew_groupnorm_apply_f16",
+    "ew_abi_version", "ew_last_error", "ew_gemm_f16", "ew_set_gemm_generation", "ew_get_gemm_generation", "ew_set_gemm_debug", "ew_gemm_last_kernel", "ew_groupnorm_stats_f16", "ew_groupnorm_apply_f16",
     "ew_layernorm_f16", "ew_attn_spatial_f16", "ew_attn_temporal_f16", "ew_nchw_f32_to_nhwc_f16",
     "ew_nhwc_f16_to_nchw_f32", "ew_euler_cfg_step", "ew_plucker_embed", "ew_cube2equi_gather",
     "ew_depth_unproject", "ew_splat_cubemap", "ew_splat_resolve", "ew_equi2pers", "ew_resize_aa_u8",
@@ -58,6 +58,7 @@ def load():
         if not hasattr(lib, s):
             raise EvoWorldHipError(f"{LIB_PATH} does not export {s}")
     lib.ew_last_error.restype = c_char_p
+    lib.ew_gemm_last_kernel.restype = c_char_p
     lib.ew_abi_version.restype = c_int
     if lib.ew_abi_version() != ABI_VERSION:
         raise EvoWorldHipError(f"ABI mismatch: library {lib.ew_abi_version()} != binding {ABI_VERSION}")

@@ -25,6 +25,8 @@ __device__ unsigned long long g2_trace[2][8][8];
 #define EW_TS(x) asm volatile("s_memtime %0" : "=s"(x))
 #endif
 
+extern char g_gemm_last_kernel[64];
+
 namespace {
 
 #define EW_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -554,6 +556,7 @@ ew_status launch2(const GemmP& p, hipStream_t s) {
     if (tiles <= 0 || tiles > 0x7fffffffLL) { ew_set_error("ew_gemm_f16: bad grid"); return EW_ERR_INVALID_ARG; }
     int grid = (NW == 8 || BM == 256) ? 256 : 512;                   // persistent: 1 x 8-wave or 2 x 4-wave workgroups per CU (256 CUs)
     if (tiles < grid) grid = (int)((tiles + 7) / 8 * 8);
+    snprintf(g_gemm_last_kernel, 64, "gemm2_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, BN, WAVES_M, WAVES_N, NSTAGE, MODE, EPI);
     hipLaunchKernelGGL((gemm2_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE, MODE, EPI>), dim3(grid), dim3(64 * NW), lds, s, q);
     return ew_check_launch("ew_gemm_f16(gen2)");
 }

@@ -18,6 +18,8 @@
 #include "gemm_common.h"
 #include <type_traits>
 
+extern char g_gemm_last_kernel[64];
+
 namespace {
 
 #define EW3_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
@@ -42,10 +44,6 @@ constexpr int NSTEP = 2 * FN;                                          // 20 ste
 #ifndef EW_G3_DIST
 #define EW_G3_DIST 2
 #endif
-#ifndef EW_G3_EARLY
-#define EW_G3_EARLY 0
-#endif
-constexpr bool EARLY = EW_G3_EARLY;                                    // two release points per K-tile (A rows at step 4, W rows at step 17)
 constexpr int PD = EW_G3_DIST;                                         // W fragments are read PD steps ahead of their MFMAs (ring of 4)
 constexpr int BAR_STEP = NSTEP - 1 - PD;                               // barrier after the step that issues the tile's last read
 
@@ -69,25 +67,22 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
     const int srow = lane >> 3;
     const int slot = (lane & 7) ^ srow;
 
-    // ---------------- loader: two independent streams (A rows, W rows), each one K-tile sequence across output tiles ------
-    // The A half of a stage is free long before the W half (all A fragments of a K-tile are read by step 3 of 20), so the two
-    // halves are staged on their own schedules (see the main loop); each stream keeps its own position in the K-tile sequence.
+    // ---------------- loader state (one K-tile ahead of the MFMA stream, across output tiles) ----------------
     constexpr int NTAP = MODE == EW_A_CONV3X3 ? 9 : (MODE == EW_A_CONVT3 ? 3 : 1);
-    int la_i = 0, la_kt = 0, la_tap = 0, la_cc = 0;   // A stream: tile step, K-tile in tile, tap, channel chunk
-    int lw_i = 0, lw_kt = 0;                          // W stream
+    int ld_i = 0, ld_kt = 0, ld_tap = 0, ld_cc = 0;
     int a_ctr[GA];                         // centre-tap pixel (row) index in the source tensors
     int a_mask[GA];                        // bits 0..8 tap validity, bits 16..27 upsample (dy,dx) codes
     const f16* b_ptr0 = p.w;               // W row of this lane's first piece (+ its 16-byte slot); piece j adds j*NW*8 rows
 
-    auto new_tile_A = [&]() __attribute__((always_inline)) {
-        const int id = la_i * G + seq0;
-        const int tm = id / p.tiles_n;
-        const int m0 = tm * BM;
+    auto loader_new_tile = [&]() __attribute__((always_inline)) {
+        const int id = ld_i * G + seq0;
+        const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
+        const int m0 = tm * BM, n0 = tn * BN;
         // per-lane constants are re-derived from an opaque copy of the lane id: hoisted out of the K-tile stream they would
         // be live across the main loop, where every VGPR is taken, and come back as scratch reloads (each with a vmcnt(0))
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
-        const int srow_o = lane_o >> 3;
+        const int srow_o = lane_o >> 3, slot_o = (lane_o & 7) ^ srow_o;
 #pragma unroll
         for (int i = 0; i < GA; ++i) {
             int m = m0 + (wave + NW * i) * 8 + srow_o;
@@ -128,69 +123,58 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
             a_mask[i] = mask | (dcode << 16);
             a_ctr[i] = ctr;
         }
-        la_kt = 0; la_tap = 0; la_cc = 0;
-    };
-    auto new_tile_W = [&]() __attribute__((always_inline)) {
-        const int id = lw_i * G + seq0;
-        const int tn = id % p.tiles_n;
-        int lane_o = lane;
-        asm volatile("" : "+v"(lane_o));
-        const int srow_o = lane_o >> 3, slot_o = (lane_o & 7) ^ srow_o;
-        b_ptr0 = p.w + (size_t)(tn * BN + wave * 8 + srow_o) * p.K + slot_o * 8;   // N % 320 == 0: every W row exists
-        lw_kt = 0;
+        b_ptr0 = p.w + (size_t)(n0 + wave * 8 + srow_o) * p.K + slot_o * 8;          // N % 320 == 0: every W row exists
+        ld_kt = 0; ld_tap = 0; ld_cc = 0;
     };
 
-    // per-K-tile state of the two streams (wave-uniform except the zero-page pointer)
-    const f16* sa_base = p.a;
+    // staging of one K-tile = stage_begin (wave-uniform source selection, advances the stream counters) + NP DMA pieces
+    const f16* st_base = p.a;
     const f16* st_zp = p.zero_page + slot * 8;
-    long long sa_dl = 0;
-    int sa_tap = 0, sa_ld = 0, sa_ch = 0;
-    char* sa_buf = smem;
-    size_t sw_koff = 0;
-    char* sw_buf = smem;
-    auto begin_A = [&](char* buf) __attribute__((always_inline)) {
-        if (la_kt == 0) new_tile_A();
-        sa_buf = buf;
-        sa_tap = la_tap;
-        const int cc = la_cc;
+    long long st_dl = 0;
+    int st_tap = 0, st_ld = 0, st_ch = 0;
+    size_t st_koff = 0;
+    char* st_buf = smem;
+    auto stage_begin = [&](char* buf) __attribute__((always_inline)) {
+        if (ld_kt == 0) loader_new_tile();
+        st_buf = buf;
+        st_tap = ld_tap;
+        const int cc = ld_cc;
         const bool second = cc >= p.c1;
-        sa_base = second ? p.a2 : p.a;
-        sa_ld = second ? p.lda2 : p.lda;
-        sa_ch = second ? cc - p.c1 : cc;
+        st_base = second ? p.a2 : p.a;
+        st_ld = second ? p.lda2 : p.lda;
+        st_ch = second ? cc - p.c1 : cc;
         int dpix = 0;                                                       // wave-uniform tap delta in pixels
-        if constexpr (MODE == EW_A_CONV3X3) dpix = (sa_tap / 3 - 1) * p.w_in + (sa_tap % 3 - 1);
-        else if constexpr (MODE == EW_A_CONVT3) dpix = (sa_tap - 1) * p.tP;
-        sa_dl = (long long)dpix * sa_ld + sa_ch;
+        if constexpr (MODE == EW_A_CONV3X3) dpix = (st_tap / 3 - 1) * p.w_in + (st_tap % 3 - 1);
+        else if constexpr (MODE == EW_A_CONVT3) dpix = (st_tap - 1) * p.tP;
+        st_dl = (long long)dpix * st_ld + st_ch;
+        st_koff = (size_t)ld_kt * BK;
         // K order: channel-chunk major, tap minor (the taps of a 64-channel chunk re-hit the same lines in L2 / TCP)
-        if (++la_tap == NTAP) { la_tap = 0; la_cc += BK; }
-        if (++la_kt == nk) { la_kt = 0; ++la_i; }
+        if (++ld_tap == NTAP) { ld_tap = 0; ld_cc += BK; }
+        if (++ld_kt == nk) { ld_kt = 0; ++ld_i; }
     };
-    auto begin_W = [&](char* buf) __attribute__((always_inline)) {
-        if (lw_kt == 0) new_tile_W();
-        sw_buf = buf;
-        sw_koff = (size_t)lw_kt * BK;
-        if (++lw_kt == nk) { lw_kt = 0; ++lw_i; }
-    };
-    auto piece_A = [&](int i) __attribute__((always_inline)) {          // i is a compile-time constant after unrolling
-        const f16* src = sa_base + ((long long)a_ctr[i] * sa_ld + (sa_dl + slot * 8));
-        if constexpr (MODE == EW_A_CONV3X3) {
-            if (p.upsample) {                                           // per-row deltas (nearest-x2 source coordinates)
-                const int dc = a_mask[i] >> 16;
-                const int dy = ((dc >> (2 * (sa_tap / 3))) & 3) - 1, dx = ((dc >> (6 + 2 * (sa_tap % 3))) & 3) - 1;
-                src = sa_base + ((long long)(a_ctr[i] + dy * p.w_in + dx) * sa_ld + (sa_ch + slot * 8));
+    auto stage_piece = [&](int k) __attribute__((always_inline)) {     // k is a compile-time constant after unrolling
+        if (k < GA) {
+            const int i = k;
+            const f16* src = st_base + ((long long)a_ctr[i] * st_ld + (st_dl + slot * 8));
+            if constexpr (MODE == EW_A_CONV3X3) {
+                if (p.upsample) {                                           // per-row deltas (nearest-x2 source coordinates)
+                    const int dc = a_mask[i] >> 16;
+                    const int dy = ((dc >> (2 * (st_tap / 3))) & 3) - 1, dx = ((dc >> (6 + 2 * (st_tap % 3))) & 3) - 1;
+                    src = st_base + ((long long)(a_ctr[i] + dy * p.w_in + dx) * st_ld + (st_ch + slot * 8));
+                }
             }
-        }
-        if constexpr (MODE != EW_A_DENSE) src = ((a_mask[i] >> sa_tap) & 1) ? src : st_zp;
+            if constexpr (MODE != EW_A_DENSE) src = ((a_mask[i] >> st_tap) & 1) ? src : st_zp;
 #if defined(EW_G3_ABLATE) && (EW_G3_ABLATE & 4)
-        asm volatile("" ::"v"(src));                                                                         // ablation: no DMA
+            asm volatile("" ::"v"(src));                                                                         // ablation: no DMA
 #else
-        glds16(src, sa_buf + (wave + NW * i) * 1024);
+            glds16(src, st_buf + (wave + NW * i) * 1024);
 #endif
-    };
-    auto piece_W = [&](int j) __attribute__((always_inline)) {
+        } else {
+            const int j = k - GA;
 #if !(defined(EW_G3_ABLATE) && (EW_G3_ABLATE & 4))
-        glds16(b_ptr0 + (size_t)(j * NW * 8) * p.K + sw_koff, sw_buf + A_BYTES + (wave + NW * j) * 1024);
+            glds16(b_ptr0 + (size_t)(j * NW * 8) * p.K + st_koff, st_buf + A_BYTES + (wave + NW * j) * 1024);
 #endif
+        }
     };
 
     // ---------------- fragment geometry ----------------
@@ -212,13 +196,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
     f16x8 bfr[4];                          // W fragment ring: step t consumes bfr[t & 3]
 
     // ---------------- prologue ----------------
-    begin_A(smem);
+    stage_begin(smem);
 #pragma unroll
-    for (int i = 0; i < GA; ++i) piece_A(i);
-    begin_W(smem);
-#pragma unroll
-    for (int j = 0; j < GB; ++j) piece_W(j);
-    int stagedA = 1, stagedW = 1;                    // K-tiles begun in each stream
+    for (int k = 0; k < NP; ++k) stage_piece(k);
+    int staged = 1;
     EW3_WAIT_VM0();
     EW3_FENCE();
     __builtin_amdgcn_s_barrier();
@@ -228,43 +209,18 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
 #pragma unroll
     for (int j = 0; j < PD; ++j) bfr[j] = EW3_LDS(smem + b_rd[0] + j * 2048);
 
-    // Staging schedule of K-tile v+2 (slot of K-tile v), steady state:
-    //   step 4 of position v : second barrier ("X") -- every wave has read all A fragments of K-tile v -> A rows of v+2, one
-    //                          piece per step over steps 4..7
-    //   step 17             : main barrier (publishes K-tile v+1, frees the W rows of K-tile v) -> W rows of v+2, one piece per
-    //                          step over steps 18, 19 and 0..2 of the next position
-    // so the feed always has the next K-tile's A rows queued behind the one being waited for (vmcnt(4) at step 17) and the
-    // LDS-DMA path never idles between a landing and the next issue (with one release point per K-tile it ran at ~40 of its
-    // ~54 GB/s per CU).  At a tile end the freed slot first hosts the epilogue patch: both halves are then staged "late", at
-    // steps 0..8 of the next position, behind the epilogue's closing barrier.
     int cur_i = 0, cur_kt = 0;
     int s_cur = 0;                                   // ring slot of stream position v
-    bool w_early = false;                            // W rows of K-tile v+1 were begun at the previous position's step 17
     for (int v = 0; v < V; ++v) {
-        char* cur = smem + s_cur * STAGE;
+        const char* cur = smem + s_cur * STAGE;
         char* nxt = smem + (s_cur ^ 1) * STAGE;
         const bool tile_end = cur_kt == nk - 1;
-        const bool has_next = v + 1 < V;
-        const bool lateA = has_next && stagedA < v + 2, lateW = has_next && stagedW < v + 2;
-        if (lateA) { begin_A(nxt); ++stagedA; }
-        if (lateW) { begin_W(nxt); ++stagedW; }
-        const bool w_cont = w_early && !lateW;       // pieces 2..4 of the W rows begun early
-        const bool doX = EARLY && !tile_end && stagedA < V;      // K-tile v+2 exists: its A rows go into this slot after step 3
-        bool w_next = false;
+        const bool pend = staged < V;                // K-tile v+1 exists: stage it into the other slot during steps 0..8
+        if (pend) { stage_begin(nxt); ++staged; }
 #pragma unroll
         for (int t = 0; t < NSTEP; ++t) {
             const int kh = t / FN, j = t - kh * FN;
-            if (t == 4) {
-                if (doX) {
-                    EW3_WAIT_LGKM0();
-                    EW3_FENCE();
-                    __builtin_amdgcn_s_barrier();
-                    EW3_FENCE();
-                    begin_A(cur);
-                    ++stagedA;
-                }
-            }
-            // ---- reads: W fragment of step t+PD (from the next K-tile once past the barrier), A fragments of the next k-half
+            // ---- reads: W fragment of step t+2 (from the next K-tile once past the barrier), A fragments of the next k-half
             if (t + PD < NSTEP) {
                 const int kh2 = (t + PD) / FN, j2 = (t + PD) - kh2 * FN;
                 bfr[(t + PD) & 3] = EW3_LDS(cur + b_rd[kh2] + j2 * 2048);
@@ -282,21 +238,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                     }
                 }
             }
-            // ---- DMA pieces of this step
-            if (t < GA) {
-                if (lateA) piece_A(t);
-            }
-            if (t < GB - 2) {
-                if (w_cont) piece_W(t + 2);
-            }
-            if (t >= GA && t < GA + GB) {
-                if (lateW) piece_W(t - GA);
-            }
-            if (t >= 4 && t < 4 + GA) {
-                if (doX) piece_A(t - 4);
-            }
-            if (t >= NSTEP - 2) {
-                if (w_next) piece_W(t - (NSTEP - 2));
+            if (t < NP) {
+                if (pend) stage_piece(t);
             }
             EW3_PIN();
 #pragma unroll
@@ -308,20 +251,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
 #endif
             EW3_PIN();
             if (t == BAR_STEP) {
-                // every fragment read of K-tile v has been issued; publish K-tile v+1 and free the W rows of this slot.
-                // Unconditional (also on the last position, where the prefetched fragments are stale and never used).
-                // In-order vmcnt: the only DMA newer than K-tile v+1 is the A half of v+2 (GA pieces) when it was issued.
-                if (doX && !lateA && !lateW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA) : "memory");
-                else EW3_WAIT_VM0();
+                // every fragment read of K-tile v has been issued; publish K-tile v+1 and free this slot.  Unconditional
+                // (also on the last position, where the prefetched fragments are stale and never used).
+                EW3_WAIT_VM0();
                 EW3_WAIT_LGKM0();
                 EW3_FENCE();
                 __builtin_amdgcn_s_barrier();
                 EW3_FENCE();
-                w_next = EARLY && !tile_end && stagedW < V;
-                if (w_next) { begin_W(cur); ++stagedW; }
             }
         }
-        w_early = w_next;
         s_cur ^= 1;
         if (++cur_kt == nk) {
             // ------------------------- epilogue of output tile cur_i -------------------------
@@ -502,6 +440,7 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
     const long long tiles = (long long)q.tiles_m * q.tiles_n;
     int grid = 256;                                   // persistent: one 8-wave workgroup per CU
     if (tiles < grid) grid = (int)((tiles + 7) / 8 * 8);
+    snprintf(g_gemm_last_kernel, 64, "gemm3_kernel<%d, %d>", MODE, EPI);
     hipLaunchKernelGGL((gemm3_kernel<MODE, EPI>), dim3(grid), dim3(64 * NW), lds, s, q);
     return ew_check_launch("ew_gemm_f16(gen3)");
 }

@@ -267,6 +267,8 @@ ew_status ew_gemm2_dispatch(const GemmP& p, hipStream_t s);   // gemm2_f16.hip
 ew_status ew_gemm3_dispatch(const GemmP& p, hipStream_t s);   // gemm3_f16.hip
 bool ew_gemm3_wants(const GemmP& p);
 static int g_gemm_gen = -1;
+char g_gemm_last_kernel[64] = "";          // rocprof-style name of the kernel the last ew_gemm_f16 call launched
+extern "C" const char* ew_gemm_last_kernel(void) { return g_gemm_last_kernel; }
 static int g_gemm_dbg = 0;
 extern "C" void ew_set_gemm_debug(int d) { g_gemm_dbg = d; }
 extern "C" void ew_set_gemm_generation(int gen) { g_gemm_gen = gen; }
@@ -325,6 +327,7 @@ extern "C" ew_status ew_gemm_f16(const ew_gemm_args* a, void* stream) {
     if (ew_get_gemm_generation() >= 3 && ew_gemm3_wants(p)) return ew_gemm3_dispatch(p, s);
     if (ew_get_gemm_generation() >= 2) return ew_gemm2_dispatch(p, s);
     // generation 1 tile choice: every channel count of the U-Net is a multiple of 160 (320*k); GEGLU and odd sizes use 128
-    if (a->act != EW_ACT_GEGLU && a->N % 160 == 0) return launch<128, 160>(p, s);
+    if (a->act != EW_ACT_GEGLU && a->N % 160 == 0) { snprintf(g_gemm_last_kernel, 64, "gemm_kernel<128, 160>"); return launch<128, 160>(p, s); }
+    snprintf(g_gemm_last_kernel, 64, "gemm_kernel<128, 128>");
     return launch<128, 128>(p, s);
 }

@@ -84,6 +84,9 @@ ew_status ew_gemm_f16(const ew_gemm_args* args, void* stream);
  * EW_GEMM_GEN overrides).  Same arguments, same results to rounding; kept selectable for A/B measurements. */
 void ew_set_gemm_generation(int gen);
 int ew_get_gemm_generation(void);
+/* Debug aid for measurement tools (bench.py): rocprof-style name of the kernel variant the last ew_gemm_f16 call on this
+   thread's library instance launched, e.g. "gemm3_kernel<0, 8>".  Not part of the reference surface. */
+const char* ew_gemm_last_kernel(void);
 void ew_set_gemm_debug(int flags);   /* measurement-only switches (bit0: skip stores, bit1: skip epilogue); 0 = normal */
 
 /* GroupNorm statistics + apply, channels-last fp16, over a (virtual) channel concat.
