@@ -1,0 +1,83 @@
+"""Analysis helper (not a test; lives under tests/ because only tests may import oracle/): how much of the HIP path's
+rel-L2 distance to the fp32 oracle is the irreducible cost of fp16 MFMA operands, and how much is fp16 STORAGE of activations?
+Runs the fp32 oracle U-Net (tiny config, CPU) three ways on the same inputs:
+  (a) operands of every conv / linear rounded to fp16 (weights too), everything else fp32   -> floor of any fp16-MFMA design
+  (b) (a) + every conv / linear / norm OUTPUT rounded to fp16                                -> what this build does
+  (c) fp32 operands but convs with TF32-like 10-bit operand mantissas                        -> what the reference's own
+      fp32 inference does on a GPU with PyTorch's default cudnn.allow_tf32=True
+Usage: python tests/analysis_fp16_floor.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from evoworld_amd.unet import DEFAULT_CONFIG, random_state_dict  # noqa: E402  (host-side weight generator only)
+from oracle.unet_ref import UNetSpatioTemporalConditionModelRef as UNetRef, tiny_config  # noqa: E402
+
+
+def rel(a, b):
+    return float((a - b).norm() / b.norm())
+
+
+def r16(t):
+    return t.to(torch.float16).to(torch.float32)
+
+
+def tf32(t):  # keep 10 explicit mantissa bits (round to nearest even on the fp32 bit pattern)
+    i = t.contiguous().view(torch.int32)
+    i = (i + 0x00000FFF + ((i >> 13) & 1)) & ~0x1FFF
+    return i.view(torch.float32)
+
+
+def run(model, inputs, pre=None, post=None, kinds_pre=(), kinds_post=()):
+    hooks = []
+    for m in model.modules():
+        if pre and isinstance(m, kinds_pre):
+            hooks.append(m.register_forward_pre_hook(lambda mod, args: tuple(pre(a) if torch.is_tensor(a) and a.is_floating_point() else a for a in args)))
+        if post and isinstance(m, kinds_post):
+            hooks.append(m.register_forward_hook(lambda mod, args, out: post(out) if torch.is_tensor(out) else out))
+    try:
+        with torch.no_grad():
+            return model(*inputs)
+    finally:
+        for h in hooks:
+            h.remove()
+
+
+def main():
+    torch.manual_seed(0)
+    cfg = tiny_config()
+    model = UNetRef(**cfg).eval()
+    g = torch.Generator().manual_seed(1)
+    model.load_state_dict({k: v.float() for k, v in random_state_dict({**DEFAULT_CONFIG, **cfg}, 0).items()}, strict=True)
+    T, h, w = cfg["num_frames"], 16, 32
+    x = torch.randn(2, T, 18, h, w, generator=g)
+    ehs = torch.randn(2, 1, cfg["cross_attention_dim"], generator=g)
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
+    inputs = (x, torch.tensor(1.234), ehs, ids)
+    mm = (torch.nn.Conv2d, torch.nn.Conv3d, torch.nn.Linear)
+    norms = (torch.nn.GroupNorm, torch.nn.LayerNorm)
+    ref = run(model, inputs)
+    w32 = {k: v.clone() for k, v in model.state_dict().items()}
+    # (c) TF32-like conv operands, fp32 linears
+    convs = (torch.nn.Conv2d, torch.nn.Conv3d)
+    for m in model.modules():
+        if isinstance(m, convs):
+            m.weight.data = tf32(m.weight.data)
+    c = run(model, inputs, pre=tf32, kinds_pre=convs)
+    model.load_state_dict(w32)
+    for m in model.modules():
+        if isinstance(m, mm):
+            m.weight.data = r16(m.weight.data)
+            if m.bias is not None:
+                m.bias.data = r16(m.bias.data)
+    a = run(model, inputs, pre=r16, kinds_pre=mm)
+    b = run(model, inputs, pre=r16, kinds_pre=mm, post=r16, kinds_post=mm + norms)
+    print(f"(a) fp16 operands only            : rel-L2 vs fp32 = {rel(a, ref):.2e}")
+    print(f"(b) fp16 operands + fp16 storage   : rel-L2 vs fp32 = {rel(b, ref):.2e}")
+    print(f"(c) TF32 conv operands (reference) : rel-L2 vs fp32 = {rel(c, ref):.2e}")
+
+
+if __name__ == "__main__":
+    main()
