@@ -206,88 +206,137 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// temporal attention: half-wave (32 lanes) per (batch, pixel, head) problem, lane = frame t
+// temporal attention: one wave per (batch, pixel, head) problem; T <= 32 frames, head_dim 64.
+// A problem's q / k / v / o are T rows of 128 bytes, S*ld apart in memory.  All global traffic is COALESCED (8 lanes per
+// 128-byte row) and staged through ONE wave-private LDS region of 32 rows x 144 B that holds, in turn, q, k, v and o
+// (144-byte rows: a lane reading its own row with ds_read_b128 is bank-conflict free).  The arithmetic is 8 MFMA 32x32x16:
+//   S^T = K Q^T   (4 MFMA; lane = query t, 16 of the 32 keys each -> lane-local softmax + one cross-half exchange)
+//   O^T = V^T P^T (4 MFMA; P stays in registers, the key order of the MFMA k-dimension follows the accumulator layout and
+//                  V^T fragments are gathered from the v rows with 16-bit LDS reads in the same order)
+// History: v1 had lane t load its own rows with eight 16-byte loads (32 lines per load instruction) and did the math on the
+// VALU with 16 KB of LDS per wave: 1.9 TB/s; coalescing alone gave 2.2 TB/s (VALU-bound); this version is HBM-bound.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                             const f16* __restrict__ v, f16* __restrict__ o, int B, int T,
-                                                            int S, int heads, int ld, int ld_o, float scale,
+                                                            int S, int heads, int ld, int ld_o, float scale_log2e,
                                                             long long n_prob) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * 2 * 2 * 32 * 128];  // [wave][prob][k|v][t][64 f16]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int half = lane >> 5, t = lane & 31;
-    const long long pid = ((long long)blockIdx.x * 4 + wave) * 2 + half;
+    __shared__ __attribute__((aligned(16))) char smem_t[4 * 32 * 144];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lh = lane >> 5, lr = lane & 31;
+    const long long pid = (long long)blockIdx.x * 4 + wave;
     const bool active = pid < n_prob;
     const long long pc = active ? pid : n_prob - 1;
     const int h = (int)(pc % heads);
     const long long bs = pc / heads;
     const int b = (int)(bs / S), s = (int)(bs - (long long)b * S);
-    const int tt = t < T ? t : T - 1;
-    const long long row = ((long long)b * T + tt) * S + s;
-    char* const kl = smem + ((wave * 2 + half) * 2 + 0) * 4096;
-    char* const vl = smem + ((wave * 2 + half) * 2 + 1) * 4096;
+    char* const reg = smem_t + wave * (32 * 144);
+    const long long row0 = (long long)b * T * S + s;                         // row of frame 0; frame r is r*S rows further
+    const int n_chunk = T * 8;
 
-    f16x8 qv[8];
-    {
-        const f16* qp = q + row * ld + h * 64;
-        const f16* kp = k + row * ld + h * 64;
-        const f16* vp = v + row * ld + h * 64;
+    // ---- all global loads first: chunk idx = it*64 + lane -> (row idx>>3, 16-byte column idx&7)
+    f16x8 tq[4], tk[4], tv[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            qv[i] = *(const f16x8*)(qp + i * 8);
-            *(f16x8*)(kl + t * 128 + i * 16) = *(const f16x8*)(kp + i * 8);
-            *(f16x8*)(vl + t * 128 + i * 16) = *(const f16x8*)(vp + i * 8);
+    for (int it = 0; it < 4; ++it) {
+        const int idx = it * 64 + lane;
+        const f16x8 z = {};
+        tq[it] = z; tk[it] = z; tv[it] = z;
+        if (idx < n_chunk) {
+            const long long off = (row0 + (long long)(idx >> 3) * S) * ld + h * 64 + (idx & 7) * 8;
+            tq[it] = *(const f16x8*)(q + off);
+            tk[it] = *(const f16x8*)(k + off);
+            tv[it] = *(const f16x8*)(v + off);
         }
     }
-    __syncthreads();
-    float sc[32];
+    auto put = [&](const f16x8 (&tt)[4]) {          // rows >= T are zero-filled (0 * garbage must not become NaN in P V)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * 64 + lane;
+            *(f16x8*)(reg + (idx >> 3) * 144 + (idx & 7) * 16) = tt[it];
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto done = [&]() {                              // every lane has consumed the region: it may be overwritten
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    };
+    // ---- operand fragments: lane (row lr, k-chunk lh) holds elements [s*16 + lh*8, +8) of its row
+    f16x8 qf[4], kf[4];
+    put(tq);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) qf[st] = *(const f16x8*)(reg + lr * 144 + st * 32 + lh * 16);
+    done();
+    put(tk);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) kf[st] = *(const f16x8*)(reg + lr * 144 + st * 32 + lh * 16);
+    done();
+    put(tv);
+
+    // ---- S^T = K Q^T: lane = query lr, keys (r&3) + 8*(r>>2) + 4*lh
+    f32x16 sacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[st], qf[st], sacc, 0, 0, 0);
     float mx = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        float a = 0.f;
-        if (j < T) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const f16x8 kv = *(const f16x8*)(kl + j * 128 + i * 16);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const h2_t x = {(__fp16)qv[i][2 * e], (__fp16)qv[i][2 * e + 1]};
-                    const h2_t y = {(__fp16)kv[2 * e], (__fp16)kv[2 * e + 1]};
-                    a = __builtin_amdgcn_fdot2(x, y, a, false);
-                }
-            }
-            a *= scale;
-            mx = fmaxf(mx, a);
-        }
-        sc[j] = a;
+    for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (key >= T) sacc[r] = -INFINITY;
+        mx = fmaxf(mx, sacc[r]);
     }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float nm = -mx * scale_log2e;
     float l = 0.f;
+    f16x8 pf[2];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const float pj = j < T ? __expf(sc[j] - mx) : 0.f;
-        sc[j] = pj;
-        l += pj;
+    for (int g2 = 0; g2 < 2; ++g2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float pe = __builtin_amdgcn_exp2f(fmaf(sacc[g2 * 8 + e], scale_log2e, nm));
+            const f16 ph = (f16)pe;
+            l += (float)ph;                                             // the normaliser sums the SAME rounded values
+            pf[g2][e] = ph;
+        }
     }
+    l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
-    f16* op = o + row * ld_o + h * 64;
+
+    // ---- O^T = V^T P^T: A fragment (row d = db*32 + lr, k-slot (g2, lh, e)) = v[key(g2, lh, e)][d]
+    f32x16 oacc[2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        float acc[8];
+    for (int db = 0; db < 2; ++db) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            if (j < T) {
-                const f16x8 vv = *(const f16x8*)(vl + j * 128 + i * 16);
+        for (int g2 = 0; g2 < 2; ++g2) {
+            f16x8 vf;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += sc[j] * (float)vv[e];
+            for (int e = 0; e < 8; ++e) {
+                const int key = 16 * g2 + 4 * lh + (e & 3) + 8 * (e >> 2);
+                vf[e] = *(const f16*)(reg + key * 144 + (db * 32 + lr) * 2);
             }
+            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[g2], oacc[db], 0, 0, 0);
         }
-        if (active && t < T) {
-            f16x8 ov;
+    }
+    done();
+    // ---- o rows into the region (lane = query lr; d = 32*db + 8*(r>>2) + 4*lh + (r&3)), then coalesced stores
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ov[e] = (f16)(acc[e] * inv);
-            *(f16x8*)(op + i * 8) = ov;
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            f16x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = (f16)(oacc[db][rq * 4 + e] * inv);
+            *(f16x4*)(reg + lr * 144 + (32 * db + 8 * rq + 4 * lh) * 2) = ov;
         }
+    done();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = it * 64 + lane;
+        if (idx < n_chunk && active)
+            *(f16x8*)(o + (row0 + (long long)(idx >> 3) * S) * ld_o + h * 64 + (idx & 7) * 8) =
+                *(const f16x8*)(reg + (idx >> 3) * 144 + (idx & 7) * 16);
     }
 }
 
@@ -314,9 +363,9 @@ extern "C" ew_status ew_attn_temporal_f16(const void* q, const void* k, const vo
     EW_REQUIRE(B > 0 && S > 0 && heads > 0 && T > 0 && T <= 32, "ew_attn_temporal_f16: need 0 < T <= 32 (T=%d)", T);
     EW_REQUIRE(ld % 8 == 0 && ld_o % 8 == 0, "ew_attn_temporal_f16: strides must be 16-byte aligned");
     const long long n_prob = (long long)B * S * heads;
-    const long long nblk = (n_prob + 7) / 8;
+    const long long nblk = (n_prob + 3) / 4;
     EW_REQUIRE(nblk < 0x7fffffffLL, "ew_attn_temporal_f16: grid too large");
     hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const f16*)q,
-                       (const f16*)k, (const f16*)v, (f16*)o, B, T, S, heads, ld, ld_o, scale, n_prob);
+                       (const f16*)k, (const f16*)v, (f16*)o, B, T, S, heads, ld, ld_o, scale * 1.4426950408889634f, n_prob);
     return ew_check_launch("ew_attn_temporal_f16");
 }
