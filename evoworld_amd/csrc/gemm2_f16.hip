@@ -491,9 +491,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
 #pragma unroll
                         for (int q = 0; q < FN / 2; ++q) {
                             const f32x4 vv = acc[i][2 * q] + bq[2 * q], gg = acc[i][2 * q + 1] + bq[2 * q + 1];
-                            f32x4 o4;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o4[e] = vv[e] * ew_gelu(gg[e]);
+                            const f32x2 o01 = ew_vgelu2((f32x2){vv[0], vv[1]}, (f32x2){gg[0], gg[1]});
+                            const f32x2 o23 = ew_vgelu2((f32x2){vv[2], vv[3]}, (f32x2){gg[2], gg[3]});
+                            const f32x4 o4 = {o01[0], o01[1], o23[0], o23[1]};
                             *(f32x4*)(patch + frow * LDO + q * 16 + fks * 4) = o4;
                             acc[i][2 * q] = (f32x4){0.f, 0.f, 0.f, 0.f};
                             acc[i][2 * q + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};

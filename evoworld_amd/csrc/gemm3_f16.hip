@@ -378,9 +378,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
 #pragma unroll
                         for (int q = 0; q < FN / 2; ++q) {
                             const f32x4 va = acc[i][2 * q] + bq[2 * q], gg = acc[i][2 * q + 1] + bq[2 * q + 1];
-                            f32x4 o4;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o4[e] = va[e] * ew_gelu(gg[e]);
+                            const f32x2 o01 = ew_vgelu2((f32x2){va[0], va[1]}, (f32x2){gg[0], gg[1]});
+                            const f32x2 o23 = ew_vgelu2((f32x2){va[2], va[3]}, (f32x2){gg[2], gg[3]});
+                            const f32x4 o4 = {o01[0], o01[1], o23[0], o23[1]};
                             *(f32x4*)(patch + frow * LDP + q * 16 + fks * 4) = o4;
                             acc[i][2 * q] = (f32x4){0.f, 0.f, 0.f, 0.f};
                             acc[i][2 * q + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
