@@ -378,8 +378,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
 #pragma unroll
                         for (int q = 0; q < FN / 2; ++q) {
                             const f32x4 va = acc[i][2 * q] + bq[2 * q], gg = acc[i][2 * q + 1] + bq[2 * q + 1];
+#ifdef EW_G3_NOGELU
+                            const f32x2 o01 = (f32x2){va[0], va[1]} * (f32x2){gg[0], gg[1]};        // measurement only: GELU cost
+                            const f32x2 o23 = (f32x2){va[2], va[3]} * (f32x2){gg[2], gg[3]};
+#else
                             const f32x2 o01 = ew_vgelu2((f32x2){va[0], va[1]}, (f32x2){gg[0], gg[1]});
                             const f32x2 o23 = ew_vgelu2((f32x2){va[2], va[3]}, (f32x2){gg[2], gg[3]});
+#endif
                             const f32x4 o4 = {o01[0], o01[1], o23[0], o23[1]};
                             *(f32x4*)(patch + frow * LDP + q * 16 + fks * 4) = o4;
                             acc[i][2 * q] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -394,7 +399,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                             const f32x4 lo = *(const f32x4*)(patch + row * LDP + c8), hi = *(const f32x4*)(patch + row * LDP + c8 + 4);
                             const f16x8 o = {(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
                             const int no = (n_w0 >> 1) + c8;
-                            if (is_live(it) && (FULL || m < p.M) && !(p.dbg & 1)) *(f16x8*)(p.out + (size_t)m * p.ld_out + no) = o;
+                            // non-temporal: the 4C-wide GEGLU output (1.2 GB at level 0) only evicts the operands from L2
+                            // (+5..6 % measured here; the same hint on the other epilogues measured -1..-18 %)
+                            if (is_live(it) && (FULL || m < p.M) && !(p.dbg & 1)) __builtin_nontemporal_store(o, (f16x8*)(p.out + (size_t)m * p.ld_out + no));
                         }
                         __builtin_amdgcn_wave_barrier();
                     }
