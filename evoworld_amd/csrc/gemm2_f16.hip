@@ -12,9 +12,11 @@
 //   * register double-buffered fragments: the ds_reads for the next MFMA half-step are issued before the current
 //     half-step's MFMAs, the first fragments of K-tile v+1 are read right after the barrier that publishes it --
 //     no LDS-latency bubble at the K-tile boundary, one barrier per K-tile;
-//   * swapped MFMA operands (D = W_frag x A_frag^T): every lane ends up with 4 consecutive output columns of one row,
-//     so the epilogue (bias / row-bias / SiLU / GEGLU / two residuals) runs straight from registers with 8-byte loads
-//     and stores -- no LDS patch, which is what lets the ring keep streaming during the epilogue.
+//   * swapped MFMA operands (D = W_frag x A_frag^T): every lane ends up with 4 consecutive output columns of one row; the
+//     epilogue (bias / row-bias / SiLU / GEGLU / two residuals) goes through a wave-private fp32 LDS patch living in the ring
+//     slot just consumed and issues 16-byte row-major stores, with the row operands requested one store step ahead;
+//   * the DMA pieces of a K-tile are issued between the MFMAs of two half-steps instead of back to back after the barrier.
+// Generation 3 (gemm3_f16.hip, 256x320 tile) is the default where it applies; this generation handles the other shapes.
 // Same argument block, same addressing modes (dense / conv3x3 / temporal 3-tap, dual source, zero page) as gen 1.
 #include "gemm_common.h"
 #include <type_traits>
