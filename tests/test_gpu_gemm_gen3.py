@@ -1,0 +1,153 @@
+"""-m gpu: the generation-3 GEMM (256x320 tile; taken when N % 320 == 0 and the problem fills the chip) against a plain
+PyTorch fp32 reference AND against the independent generation-1 kernels, on problems large enough to be routed to it:
+ragged M (edge tiles), every epilogue operand set that occurs in the U-Net, all three A addressing modes (dense, conv3x3 with
+stride / upsample / dual source, temporal 3-tap).  test_gpu_ops.py's GEMM cases are small and run on generation 2."""
+import ctypes
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from evoworld_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from evoworld_amd import _lib
+    L = _lib.load()
+    L.ew_set_gemm_generation.argtypes = [ctypes.c_int]
+    yield L
+    L.ew_set_gemm_generation(3)
+
+
+def both(lib, fn):
+    """Run fn under generation 3 (asserting that generation 3 really took the problem) and under generation 1."""
+    lib.ew_set_gemm_generation(3)
+    a = fn().clone()
+    assert lib.ew_gemm_last_kernel().decode().startswith("gemm3_kernel"), lib.ew_gemm_last_kernel()
+    lib.ew_set_gemm_generation(1)
+    b = fn().clone()
+    assert lib.ew_gemm_last_kernel().decode().startswith("gemm_kernel")
+    lib.ew_set_gemm_generation(3)
+    return a, b
+
+
+@pytest.mark.parametrize("M,N,K,eps", [(51237, 320, 320, "bias"), (26011, 640, 192, "rb+r1"), (26000, 640, 128, "r1+r2"),
+                                        (51456, 320, 64, "silu"), (25700, 640, 448, "rb"), (30000, 960, 64, "rb+r1+r2")])
+def test_dense_epilogues(ops, lib, M, N, K, eps):
+    x, w, b = rnd(M, K, seed=1).half().to(DEV), (rnd(N, K, seed=2) / math.sqrt(K)).half().to(DEV), rnd(N, seed=3).half().to(DEV)
+    rpg = 7001
+    G = M // rpg + 1
+    rb = rnd(G, N + 64, seed=4).half().to(DEV) if "rb" in eps else None
+    r1 = rnd(M, N, seed=5).half().to(DEV) if "r1" in eps else None
+    r2 = rnd(M, N + 8, seed=6).half().to(DEV) if "r2" in eps else None
+    act = ops.ACT_SILU if eps == "silu" else ops.ACT_NONE
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+
+    def run():
+        return ops.gemm(x, w, out, M=M, N=N, c1=K, lda=K, bias=b, rowbias=None if rb is None else rb[:, 64:],
+                        ld_rowbias=N + 64, rows_per_group=rpg, r1=r1, ld_r1=N, r2=r2, ld_r2=N + 8, act=act,
+                        c_acc=0.7, c_r1=0.6, c_r2=-1.5)
+    g3, g1 = both(lib, run)
+    y = x.float() @ w.float().T + b.float()
+    if rb is not None:
+        y = y + rb[:, 64:].float()[torch.arange(M, device=DEV) // rpg]
+    if act:
+        y = F.silu(y)
+    y = 0.7 * y
+    if r1 is not None:
+        y = y + 0.6 * r1.float()
+    if r2 is not None:
+        y = y - 1.5 * r2[:, :N].float()
+    assert rel_l2(g3.float().cpu(), y.cpu()) < 1e-3
+    assert rel_l2(g3.float().cpu(), g1.float().cpu()) < 1e-3
+
+
+def test_geglu(ops, lib):
+    M, C = 25700, 80                                     # N = 8C = 640
+    x = rnd(M, C, seed=1).half().to(DEV)
+    w, b = (rnd(8 * C, C, seed=2) / 8).half().to(DEV), rnd(8 * C, seed=3).half().to(DEV)
+    x = F.pad(x, (0, 48))                                # K padded to 128 (c1 % 64 == 0)
+    w = F.pad(w, (0, 48))
+    n = 4 * C
+    idx = torch.arange(2 * n).reshape(2, n // 16, 16).permute(1, 0, 2).reshape(-1).to(DEV)
+    wp, bp = w[idx].contiguous(), b[idx].contiguous()
+    g3, g1 = both(lib, lambda: ops.linear(x, wp, bp, act=ops.ACT_GEGLU))
+    y = x.float() @ w.float().T + b.float()
+    ref = y[:, :n] * F.gelu(y[:, n:])
+    assert g3.shape == (M, n)
+    assert rel_l2(g3.float().cpu(), ref.cpu()) < 1e-3
+    assert rel_l2(g3.float().cpu(), g1.float().cpu()) < 1e-3
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).half().contiguous().to(DEV)
+
+
+def _pack3(w):
+    from evoworld_amd.ops import pack_conv_weight
+    return pack_conv_weight(w.half().float()).to(DEV)
+
+
+@pytest.mark.parametrize("N,C,c2,O,H,W,stride,up,eps", [(13, 64, 0, 320, 61, 65, 1, 0, "rb"), (7, 64, 64, 320, 44, 170, 1, 0, "r1"),
+                                                          (5, 64, 0, 320, 50, 52, 1, 1, "bias"), (20, 128, 0, 640, 74, 70, 2, 0, "bias")])
+def test_conv3x3(ops, lib, N, C, c2, O, H, W, stride, up, eps):
+    x1, x2 = rnd(N, C, H, W, seed=1), (rnd(N, c2, H, W, seed=7) if c2 else None)
+    w, b = rnd(O, C + c2, 3, 3, seed=2) / math.sqrt(9 * (C + c2)), rnd(O, seed=3)
+    xin = torch.cat([x1, x2], 1) if c2 else x1
+    xin = xin.half().float()
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin.to(DEV), w.half().float().to(DEV), b.half().float().to(DEV), stride=stride, padding=1)
+    Ho, Wo = ref.shape[-2:]
+    M = N * Ho * Wo
+    rpg = 3 * Ho * Wo
+    rb = rnd(M // rpg + 1, O, seed=4).half().to(DEV) if eps == "rb" else None
+    r1 = rnd(M, O, seed=5).half().to(DEV) if eps == "r1" else None
+    out = torch.empty(M, O, dtype=torch.float16, device=DEV)
+    a1, a2 = _nhwc(x1), (_nhwc(x2) if c2 else None)
+    wp, bh = _pack3(w), b.half().to(DEV)
+
+    def run():
+        return ops.gemm(a1, wp, out, M=M, N=O, c1=C, lda=C, a2=a2, c2=c2, lda2=c2, bias=bh, rowbias=rb, ld_rowbias=O,
+                        rows_per_group=rpg, r1=r1, ld_r1=O, mode=ops.A_CONV3X3, conv=(N, H, W, Ho, Wo, stride, up))
+    g3, g1 = both(lib, run)
+    y = ref.permute(0, 2, 3, 1).reshape(M, O)
+    if rb is not None:
+        y = y + rb.float()[torch.arange(M, device=DEV) // rpg]
+    if r1 is not None:
+        y = y + r1.float()
+    assert rel_l2(g3.float().cpu(), y.cpu()) < 1e-3
+    assert rel_l2(g3.float().cpu(), g1.float().cpu()) < 1e-3
+
+
+def test_conv_temporal(ops, lib):
+    B, T, P, C, O = 2, 25, 1031, 64, 320
+    x = rnd(B, T, P, C, seed=1)
+    w, b = rnd(O, C, 3, 1, 1, seed=2) / math.sqrt(3 * C), rnd(O, seed=3)
+    xr = x.half().float().permute(0, 3, 1, 2).unsqueeze(-1)           # [B,C,T,P,1]
+    ref = F.conv3d(xr.to(DEV), w.half().float().to(DEV), b.half().float().to(DEV), padding=(1, 0, 0))
+    ref = ref.squeeze(-1).permute(0, 2, 3, 1).reshape(B * T * P, O)
+    wp = _pack3(w)                                                     # [O,C,3,1,1] -> chunk-major / tap-minor
+    xin = x.reshape(B * T * P, C).half().to(DEV)
+    r1 = rnd(B * T * P, O, seed=5).half().to(DEV)
+    out = torch.empty(B * T * P, O, dtype=torch.float16, device=DEV)
+    g3, g1 = both(lib, lambda: ops.gemm(xin, wp, out, M=B * T * P, N=O, c1=C, lda=C, bias=b.half().to(DEV), r1=r1, ld_r1=O,
+                                        c_acc=0.3, mode=ops.A_CONVT3, tconv=(B, T, P)))
+    y = 0.3 * ref + r1.float()
+    assert rel_l2(g3.float().cpu(), y.cpu()) < 1e-3
+    assert rel_l2(g3.float().cpu(), g1.float().cpu()) < 1e-3
