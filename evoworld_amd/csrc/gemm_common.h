@@ -19,6 +19,7 @@ struct GemmP {
     int rows_per_group, act;
     float c_acc, c_r1, c_r2;
     int tiles_m, tiles_n;
+    int band;  // generation 3: tile columns per band of the tile order (0 = plain tn-fastest order)
     int dbg;   // experiment switches (tools/bench_kernels.py): bit0 skip output stores, bit1 skip epilogue entirely
 };
 

@@ -321,6 +321,7 @@ extern "C" ew_status ew_gemm_f16(const ew_gemm_args* a, void* stream) {
     p.stride = a->stride; p.upsample = a->upsample; p.tB = a->tB; p.tT = a->tT; p.tP = a->tP;
     p.rows_per_group = a->rows_per_group; p.act = a->act; p.c_acc = a->c_acc; p.c_r1 = a->c_r1; p.c_r2 = a->c_r2;
     p.tiles_m = p.tiles_n = 0;
+    p.band = 0;
     p.dbg = g_gemm_dbg;
     hipStream_t s = (hipStream_t)stream;
     // generation 3 (256x320 tile) where it applies and fills the chip, generation 2 otherwise
