@@ -227,6 +227,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     D.barrier()
+    D.shutdown()
 
 
 if __name__ == "__main__":

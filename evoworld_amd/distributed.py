@@ -13,7 +13,8 @@ def init(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("EW_FORCE_DIST") == "1" and "MASTER_PORT" in os.environ   # test hook: exercise RCCL with one rank
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
@@ -29,9 +30,13 @@ def shard_clips(n_clips, rank, world):
     return list(range(rank, n_clips, world))
 
 
+def _single():
+    return not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and os.environ.get("EW_FORCE_DIST") != "1")
+
+
 def broadcast_tensors(tensors, src=0):
     """One-time weight broadcast (packed fp16 weights, 3.04 GB for the full U-Net) from `src` to all ranks."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _single():
         return tensors
     for t in tensors:
         dist.broadcast(t, src=src)
@@ -40,7 +45,7 @@ def broadcast_tensors(tensors, src=0):
 
 def gather_results(x):
     """all_gather of a per-rank result tensor (final latents [1,T,4,h,w] fp32 = 3.7 MB per clip) -> list, rank order."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _single():
         return [x]
     out = [torch.empty_like(x) for _ in range(dist.get_world_size())]
     dist.all_gather(out, x.contiguous())
@@ -48,13 +53,18 @@ def gather_results(x):
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if not _single():
         dist.barrier()
 
 
 def max_over_ranks(value, device):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _single():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def shutdown():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()

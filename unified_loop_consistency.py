@@ -142,6 +142,7 @@ def main(argv=None):
         report.append({"episode": os.path.basename(ep), "frames": int(frames.shape[0]), "seconds": round(dt, 3), "rank": rank})
         print(json.dumps(report[-1]), flush=True)
     D.barrier()
+    D.shutdown()
     return report
 
 
