@@ -308,7 +308,55 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                 constexpr int VPR = CP / 8;                 // 16-byte output vectors per row and pass
                 constexpr int ITERS = (16 * VPR + 63) / 64;  // 3 (the last one partial: 160 = 2*64 + 32)
                 auto is_live = [&](int it) { return it * 64 + lane < 16 * VPR; };
-                if constexpr ((EPI & 8) == 0) {
+                if constexpr ((EPI & ~1) == 0) {
+                    // No residual operands: bias / row-bias / SiLU / scale are applied in the ACCUMULATOR layout (4 consecutive
+                    // columns per lane: 8-byte operand loads of L2-resident vectors) and the result goes through the patch as
+                    // fp16 -- half the LDS bytes of the fp32 patch, no conversion after the read-back.  Same values, rounded
+                    // once, as the general path below.
+                    constexpr bool RB = EPI & 1;
+                    constexpr int NH = WN / CP;
+                    constexpr int LDH = CP + 8;              // patch row stride in halfs (176 B)
+                    f16* patch16 = (f16*)patch;
+                    const int rpg = p.rows_per_group;
+                    const bool silu = p.act == EW_ACT_SILU;
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+                        const int m_l = min(m_w0 + i * 16 + frow, p.M - 1);
+                        const int g = RB ? m_l / rpg : 0;
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) {
+#pragma unroll
+                            for (int jj = 0; jj < CP / 16; ++jj) {
+                                const int j = h * (CP / 16) + jj;
+                                const int n = n_w0 + j * 16 + fks * 4;
+                                const f16x4 b4 = *(const f16x4*)((const char*)bp + (unsigned)(n * mbias) * 2u);
+                                f32x4 x = acc[i][j] + (f32x4){(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
+                                if constexpr (RB) {
+                                    const f16x4 r4 = *(const f16x4*)((const char*)rbp + (unsigned)(g * ldrb + n * mrb) * 2u);
+                                    x += (f32x4){(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
+                                }
+                                if (silu) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) x[e] = ew_silu(x[e]);
+                                }
+                                x *= p.c_acc;
+                                const f16x4 o4 = {(f16)x[0], (f16)x[1], (f16)x[2], (f16)x[3]};
+                                *(f16x4*)(patch16 + frow * LDH + jj * 16 + fks * 4) = o4;
+                                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            }
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int it = 0; it < ITERS; ++it) {
+                                const int idx = it * 64 + lane;
+                                const int row = is_live(it) ? idx / VPR : 0, c8 = is_live(it) ? (idx - row * VPR) * 8 : 0;
+                                const int m = m_w0 + i * 16 + row, n = n_w0 + h * CP + c8;
+                                const f16x8 o = *(const f16x8*)(patch16 + row * LDH + c8);
+                                if (is_live(it) && (FULL || m < p.M) && !(p.dbg & 1)) *(f16x8*)((char*)p.out + (unsigned)(m * p.ld_out + n) * 2u) = o;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                } else if constexpr ((EPI & 8) == 0) {
                     constexpr bool RB = EPI & 1, R1 = EPI & 2, R2 = EPI & 4;
                     constexpr int NH = WN / CP;              // 2 column passes
                     int rowv[ITERS], c8v[ITERS];
@@ -405,8 +453,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                             const f32x2 o01 = ew_vgelu2((f32x2){va[0], va[1]}, (f32x2){gg[0], gg[1]});
                             const f32x2 o23 = ew_vgelu2((f32x2){va[2], va[3]}, (f32x2){gg[2], gg[3]});
 #endif
-                            const f32x4 o4 = {o01[0], o01[1], o23[0], o23[1]};
-                            *(f32x4*)(patch + frow * LDP + q * 16 + fks * 4) = o4;
+                            const f16x4 o4 = {(f16)o01[0], (f16)o01[1], (f16)o23[0], (f16)o23[1]};
+                            *(f16x4*)((f16*)patch + frow * (CP + 8) + q * 16 + fks * 4) = o4;      // fp16 patch, row stride 176 B
                             acc[i][2 * q] = (f32x4){0.f, 0.f, 0.f, 0.f};
                             acc[i][2 * q + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
                         }
@@ -416,8 +464,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                             const int idx = it * 64 + lane;
                             const int row = is_live(it) ? idx / VPR : 0, c8 = is_live(it) ? (idx - row * VPR) * 8 : 0;
                             const int m = m_w0 + i * 16 + row;
-                            const f32x4 lo = *(const f32x4*)(patch + row * LDP + c8), hi = *(const f32x4*)(patch + row * LDP + c8 + 4);
-                            const f16x8 o = {(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
+                            const f16x8 o = *(const f16x8*)((const f16*)patch + row * (CP + 8) + c8);
                             const int no = (n_w0 >> 1) + c8;
                             // non-temporal: the 4C-wide GEGLU output (1.2 GB at level 0) only evicts the operands from L2
                             // (+5..6 % measured here; the same hint on the other epilogues measured -1..-18 %)
