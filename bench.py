@@ -43,9 +43,10 @@ def synth_inputs(T, h, w, seed, device):
 
 def cpu_baseline(max_threads=32):
     """The reference's CPU path (diffusers fp32 on PyTorch) restated by the oracle, timed on the host cores on a
-    BOUNDED sample: one full-resolution (72x128 latents) U-Net forward over ONE frame of ONE CFG row (B=1, T=1), incl. the
-    reference's dead cross-attention work.  Per-frame cost is linear in B*T (spatial attention/convs are per frame, the
-    temporal parts are linear in T), so a clip step (B=2, T=25) = 50 samples.  Threads are capped: torch's CPU convs do
+    BOUNDED sample (~15-20 s of CPU work): one full-resolution (72x128 latents) U-Net forward over FOUR frames of ONE CFG row
+    (B=1, T=4, so the temporal convs / temporal attention see more than one frame), incl. the reference's dead
+    cross-attention work.  Per-frame cost is linear in B*T (spatial attention/convs are per frame, the temporal parts are
+    linear in T up to the small T^2 attention term), so a clip step (B=2, T=25) = 12.5 samples.  Threads are capped: torch's CPU convs do
     not scale past a few dozen threads on this problem (256 threads measured 20x slower than the cap)."""
     from oracle.unet_ref import UNetSpatioTemporalConditionModelRef
     cores = min(os.cpu_count() or 1, max_threads)
@@ -57,17 +58,18 @@ def cpu_baseline(max_threads=32):
         for p in m.parameters():
             p.fill_(0.01)                      # timing only: values do not matter, denormals/NaNs must be avoided
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(1, 1, 18, 72, 128, generator=g)
+    TS = 4
+    x = torch.randn(1, TS, 18, 72, 128, generator=g)
     ehs = torch.randn(1, 1, 1024, generator=g)
     ids = torch.tensor([[6.0, 127.0, 0.02]])
     t0 = time.time()
     m(x, torch.tensor(1.0), ehs, ids, exec_dead_cross_attn=True)
     dt = time.time() - t0
-    t_forward = dt * 50.0
+    t_forward = dt * 50.0 / TS
     fps = 25.0 / (25 * t_forward)
     return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 fp32 oracle U-Net forward at 72x128 latents over B=1 x T=1 frame ({dt:.1f} s on {cores} threads), "
-                      "scaled x50 to B=2,T=25 and x25 denoise steps per clip"}
+            "sample": f"1 fp32 oracle U-Net forward at 72x128 latents over B=1 x T={TS} frames ({dt:.1f} s on {cores} threads), "
+                      f"scaled x{50 / TS:g} to B=2,T=25 and x25 denoise steps per clip"}
 
 
 def kernel_breakdown(unet, pipe, latents, image_latents, ehs, plucker, T, h, w, top=8):
