@@ -1,0 +1,524 @@
+// gemm4_f16.hip -- generation 4 (EXPERIMENT, selected with EW_GEMM_GEN=4): generation 3's tile, loader and epilogue with a
+// PING-PONG main loop.  The two waves that share a SIMD (w and w+4) belong to two groups that run the same program one
+// interval apart: while one group issues its 40 MFMAs of a k-half ("compute"), the other reads the 14 fragments of its next
+// k-half from LDS and issues its LDS-DMA pieces ("memory"); a workgroup barrier separates the intervals.  Fragments are
+// loaded while the wave has no MFMA in flight, so one fragment set (56 VGPRs) suffices next to the 160 accumulators, and
+// the MFMA pipe always has exactly one wave feeding it.  The epilogue patch lives in its own 11 KB region behind the two
+// 72 KB stages (four waves use it at a time), so the LDS-DMA of the next K-tile never has to wait for an epilogue.
+// Built for the operand sets with an fp16 patch (bias / row-bias / GEGLU); other problems stay on generation 3.
+//
+// RESULT (tools/experiments/exp31_gen4.py, in-process A/B): bit-identical to generation 3 and 0.5-4 % SLOWER on the large-K
+// problems (1100-1200 TF/s either way), 11-18 % slower on the short-K ones.  Two unrelated schedules landing on the same
+// rate says the large-K kernels sit on a hardware ceiling (sustained clock under MFMA load / LDS + DMA feed), not on
+// instruction scheduling.  Not part of the build: to try it again, copy it to evoworld_amd/csrc/, add gemm4_f16.o to OBJS and
+// route `ew_get_gemm_generation() >= 4 && ew_gemm4_wants(p)` to ew_gemm4_dispatch in gemm_f16.hip.
+#include "gemm_common.h"
+#include <type_traits>
+
+extern char g_gemm_last_kernel[64];
+
+namespace {
+
+#define EW3_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
+#define EW3_FENCE() asm volatile("" ::: "memory")
+#define EW3_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#if defined(EW_G3_ABLATE) && (EW_G3_ABLATE & 2)
+#define EW3_LDS(ptr) (f16x8{})                       /* ablation: no ds_reads */
+#else
+#define EW3_LDS(ptr) (*(const f16x8*)(ptr))
+#endif
+
+constexpr int BM = 256, BN = 320, BK = 64, NW = 8, WAVES_N = 2;
+constexpr int WM = 64, WN = 160, FM = 4, FN = 10;
+constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW, NP = GA + GB;        // 4 + 5 DMA pieces per wave per K-tile
+constexpr int NSTEP = 2 * FN;                                          // 20 steps (k-half, W fragment) per K-tile
+#ifdef EW_G3_NOPIN
+#define EW3_PIN()
+#else
+#define EW3_PIN() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifndef EW_G3_DIST
+#define EW_G3_DIST 2
+#endif
+constexpr int PD = EW_G3_DIST;                                         // W fragments are read PD steps ahead of their MFMAs (ring of 4)
+constexpr int BAR_STEP = NSTEP - 1 - PD;
+constexpr int PATCH_BYTES = 16 * (80 + 8) * 2;                         // fp16 patch of one wave: 16 rows x 176 B                               // barrier after the step that issues the tile's last read
+
+// Tile id -> (tm, tn).  Ids are consumed in XCD-contiguous chunks of 32 (one per CU of an XCD at a time), so 32 consecutive ids
+// should form a 2-D block that shares as many operand rows as possible in that XCD's 4 MB L2.  With more than BAND tile
+// columns a plain "tn fastest" order makes a chunk one M-tile x 32 N-tiles: every chunk streams 32 different W slices (the
+// whole weight matrix at N = 10240) through L2 -- measured FETCH_SIZE 3.0 GB against 0.10 GB algorithmic for the level-2
+// GEGLU GEMM.  Bands of BAND tile columns make a chunk (32 / BAND) M-tiles x BAND N-tiles.
+// Each A row-tile is then fetched once per band instead of once, so banding is only switched on when the weight matrix does
+// not fit in L2 anyway (launch4: W > 3 MB; at level 0, W = 1.6 MB, bands measured -7 %, at level 2, 26 MB, +6 %).
+__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int band, int& tm, int& tn) {
+    if (band <= 0 || tiles_n <= band) { tm = id / tiles_n; tn = id - tm * tiles_n; return; }
+    const int nb = (tiles_n + band - 1) / band;
+    const int per_band = band * tiles_m;
+    const int k = min(id / per_band, nb - 1);
+    const int r = id - k * per_band;
+    const int w = k == nb - 1 ? tiles_n - k * band : band;
+    tm = r / w;
+    tn = k * band + (r - tm * w);
+}
+
+template <int MODE, int EPI>
+__global__ __launch_bounds__(64 * NW, 2) void gemm4_kernel(const GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+
+    // ---- tile sequence of this persistent block: step i -> tile id i*G + (b%8)*(G/8) + b/8  (XCD-contiguous chunks)
+    const int G = gridDim.x;
+    const int total_tiles = p.tiles_m * p.tiles_n;
+    const int seq0 = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int n_my = seq0 < total_tiles ? (total_tiles - 1 - seq0) / G + 1 : 0;
+    const int nk = p.K / BK;
+    const int V = n_my * nk;                                           // K-tile stream length of this block
+    if (V == 0) return;
+
+    const int srow = lane >> 3;
+    const int slot = (lane & 7) ^ srow;
+
+    // ---------------- loader state (one K-tile ahead of the MFMA stream, across output tiles) ----------------
+    constexpr int NTAP = MODE == EW_A_CONV3X3 ? 9 : (MODE == EW_A_CONVT3 ? 3 : 1);
+    int ld_i = 0, ld_kt = 0, ld_tap = 0, ld_cc = 0;
+    int a_ctr[GA];                         // centre-tap pixel (row) index in the source tensors
+    int a_mask[GA];                        // bits 0..8 tap validity, bits 16..27 upsample (dy,dx) codes
+    const f16* b_ptr0 = p.w;               // W row of this lane's first piece (+ its 16-byte slot); piece j adds j*NW*8 rows
+
+    auto loader_new_tile = [&]() __attribute__((always_inline)) {
+        const int id = ld_i * G + seq0;
+        int tm, tn;
+        tile_coords(id, p.tiles_m, p.tiles_n, p.band, tm, tn);
+        const int m0 = tm * BM, n0 = tn * BN;
+        // per-lane constants are re-derived from an opaque copy of the lane id: hoisted out of the K-tile stream they would
+        // be live across the main loop, where every VGPR is taken, and come back as scratch reloads (each with a vmcnt(0))
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int srow_o = lane_o >> 3, slot_o = (lane_o & 7) ^ srow_o;
+#pragma unroll
+        for (int i = 0; i < GA; ++i) {
+            int m = m0 + (wave + NW * i) * 8 + srow_o;
+            m = m < p.M ? m : p.M - 1;
+            int ctr, mask = 1, dcode = 0;
+            if constexpr (MODE == EW_A_CONV3X3) {
+                const int hw = p.h_out * p.w_out;
+                const int img = m / hw, rem = m - img * hw;
+                const int oy = rem / p.w_out, ox = rem - oy * p.w_out;
+                const int hlim = p.upsample ? 2 * p.h_in : p.h_in, wlim = p.upsample ? 2 * p.w_in : p.w_in;
+                const int cy = oy * p.stride, cx = ox * p.stride;               // centre tap, in (possibly upsampled) input coords
+                mask = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
+                    if (iy >= 0 && iy < hlim && ix >= 0 && ix < wlim) mask |= 1 << t;
+                }
+                if (p.upsample) {
+                    const int sy = cy >> 1, sx = cx >> 1;                        // source pixel of the centre tap
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        dcode |= ((((cy + k - 1) >> 1) - sy) + 1) << (2 * k);        // dy(ky) in {-1,0,1} -> 2 bits
+                        dcode |= ((((cx + k - 1) >> 1) - sx) + 1) << (6 + 2 * k);    // dx(kx)
+                    }
+                    ctr = (img * p.h_in + sy) * p.w_in + sx;
+                } else {
+                    ctr = (img * p.h_in + cy) * p.w_in + cx;
+                }
+            } else if constexpr (MODE == EW_A_CONVT3) {
+                const int tp = p.tT * p.tP;
+                const int bb = m / tp, rem = m - bb * tp;
+                const int t = rem / p.tP, x = rem - t * p.tP;
+                mask = (t > 0 ? 1 : 0) | 2 | (t + 1 < p.tT ? 4 : 0);
+                ctr = (bb * p.tT + t) * p.tP + x;
+            } else {
+                ctr = m;
+            }
+            a_mask[i] = mask | (dcode << 16);
+            a_ctr[i] = ctr;
+        }
+        b_ptr0 = p.w + (size_t)(n0 + wave * 8 + srow_o) * p.K + slot_o * 8;          // N % 320 == 0: every W row exists
+        ld_kt = 0; ld_tap = 0; ld_cc = 0;
+    };
+
+    // staging of one K-tile = stage_begin (wave-uniform source selection, advances the stream counters) + NP DMA pieces
+    const f16* st_base = p.a;
+    const f16* st_zp = p.zero_page + slot * 8;
+    long long st_dl = 0;
+    int st_tap = 0, st_ld = 0, st_ch = 0;
+    size_t st_koff = 0;
+    char* st_buf = smem;
+    auto stage_begin = [&](char* buf) __attribute__((always_inline)) {
+        if (ld_kt == 0) loader_new_tile();
+        st_buf = buf;
+        st_tap = ld_tap;
+        const int cc = ld_cc;
+        const bool second = cc >= p.c1;
+        st_base = second ? p.a2 : p.a;
+        st_ld = second ? p.lda2 : p.lda;
+        st_ch = second ? cc - p.c1 : cc;
+        int dpix = 0;                                                       // wave-uniform tap delta in pixels
+        if constexpr (MODE == EW_A_CONV3X3) dpix = (st_tap / 3 - 1) * p.w_in + (st_tap % 3 - 1);
+        else if constexpr (MODE == EW_A_CONVT3) dpix = (st_tap - 1) * p.tP;
+        st_dl = (long long)dpix * st_ld + st_ch;
+        st_koff = (size_t)ld_kt * BK;
+        // K order: channel-chunk major, tap minor (the taps of a 64-channel chunk re-hit the same lines in L2 / TCP)
+        if (++ld_tap == NTAP) { ld_tap = 0; ld_cc += BK; }
+        if (++ld_kt == nk) { ld_kt = 0; ++ld_i; }
+    };
+    auto stage_piece = [&](int k) __attribute__((always_inline)) {     // k is a compile-time constant after unrolling
+        if (k < GA) {
+            const int i = k;
+            const f16* src = st_base + ((long long)a_ctr[i] * st_ld + (st_dl + slot * 8));
+            if constexpr (MODE == EW_A_CONV3X3) {
+                if (p.upsample) {                                           // per-row deltas (nearest-x2 source coordinates)
+                    const int dc = a_mask[i] >> 16;
+                    const int dy = ((dc >> (2 * (st_tap / 3))) & 3) - 1, dx = ((dc >> (6 + 2 * (st_tap % 3))) & 3) - 1;
+                    src = st_base + ((long long)(a_ctr[i] + dy * p.w_in + dx) * st_ld + (st_ch + slot * 8));
+                }
+            }
+            if constexpr (MODE != EW_A_DENSE) src = ((a_mask[i] >> st_tap) & 1) ? src : st_zp;
+#if defined(EW_G3_ABLATE) && (EW_G3_ABLATE & 4)
+            asm volatile("" ::"v"(src));                                                                         // ablation: no DMA
+#else
+            glds16(src, st_buf + (wave + NW * i) * 1024);
+#endif
+        } else {
+            const int j = k - GA;
+#if !(defined(EW_G3_ABLATE) && (EW_G3_ABLATE & 4))
+            glds16(b_ptr0 + (size_t)(j * NW * 8) * p.K + st_koff, st_buf + A_BYTES + (wave + NW * j) * 1024);
+#endif
+        }
+    };
+
+    // ---------------- fragment geometry ----------------
+    const int frow = lane & 15, fks = lane >> 4, sw = frow & 7;
+    int a_rd[2], b_rd[2];                  // per-lane byte offset inside a stage of A fragment 0 / W fragment 0, per k-half
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        const int so = ((kh * 4 + fks) ^ sw) << 4;
+        a_rd[kh] = (wm * WM + frow) * 128 + so;
+        b_rd[kh] = A_BYTES + (wn * WN + frow) * 128 + so;
+    }
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f16x8 af[FM], bf[FN];                  // the fragments of ONE k-half (loaded in a memory interval, consumed in the next)
+    const int grp = wave >> 2;             // waves w and w+4 share a SIMD: group 1 runs one interval behind group 0
+    auto sync = [&]() __attribute__((always_inline)) {
+        EW3_WAIT_LGKM0();
+        EW3_FENCE();
+        __builtin_amdgcn_s_barrier();
+        EW3_FENCE();
+    };
+    auto mem = [&](const char* st, int kh) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = EW3_LDS(st + a_rd[kh] + i * 2048);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bf[j] = EW3_LDS(st + b_rd[kh] + j * 2048);
+    };
+    auto compute = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // D[n][m]
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---------------- prologue ----------------
+    stage_begin(smem);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) stage_piece(k);
+    int staged = 1;
+    EW3_WAIT_VM0();
+    EW3_FENCE();
+    __builtin_amdgcn_s_barrier();
+    EW3_FENCE();
+    if (grp == 1) sync();                  // delay: group 1 executes every interval one barrier later than group 0
+
+    int cur_i = 0, cur_kt = 0;
+    int s_cur = 0;                                   // ring slot of stream position v
+    for (int v = 0; v < V; ++v) {
+        const char* cur = smem + s_cur * STAGE;
+        char* nxt = smem + (s_cur ^ 1) * STAGE;
+        // ---- interval 1 (memory): fragments of k-half 0; stage K-tile v+1 into the other slot (its last reader, the other
+        //      group's k-half-1 read of K-tile v-1, finished before the barrier that opened this interval)
+        const bool pend = staged < V;
+        if (pend) { stage_begin(nxt); ++staged; }
+        mem(cur, 0);
+        if (pend) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) stage_piece(k);
+        }
+        sync();
+        // ---- interval 2 (compute)
+        compute();
+        sync();
+        // ---- interval 3 (memory): fragments of k-half 1; own DMA pieces (issued two intervals ago) must have landed before
+        //      the barrier that lets the other group's last reader through
+        mem(cur, 1);
+        EW3_WAIT_VM0();
+        sync();
+        // ---- interval 4 (compute)
+        compute();
+        sync();
+        s_cur ^= 1;
+        if (++cur_kt == nk) {
+            // ------------------------- epilogue of output tile cur_i -------------------------
+            cur_kt = 0;
+            const int id = cur_i * G + seq0;
+            ++cur_i;
+            int tm, tn;
+            tile_coords(id, p.tiles_m, p.tiles_n, p.band, tm, tn);
+            const bool full = (tm * BM + wm * WM + WM <= p.M);          // N is always full (N % 320 == 0)
+            // wave-private fp32 patch in the slot just consumed (free since the barrier of step 17; the DMA of the next
+            // K-tile into it is issued by the NEXT position, after the closing barrier below)
+            constexpr int CP = 80;                                 // columns per pass
+            constexpr int LDP = CP + 4;                            // patch row stride (floats)
+            float* patch = (float*)(smem + 2 * STAGE + (wave & 3) * PATCH_BYTES);
+            const int m_w0 = tm * BM + wm * WM, n_w0 = tn * BN + wn * WN;
+            auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                int lane = tid & 63;                        // opaque copy: keeps the epilogue's per-lane constants out of the main loop
+                asm volatile("" : "+v"(lane));
+                const int frow = lane & 15, fks = lane >> 4;
+                const f16* bp = p.bias ? p.bias : p.zero_page;
+                const f16* rbp = p.rowbias ? p.rowbias : p.zero_page;
+                const f16* r1p = p.r1 ? p.r1 : p.zero_page;
+                const f16* r2p = p.r2 ? p.r2 : p.zero_page;
+                const int mbias = p.bias ? 1 : 0, mrb = p.rowbias ? 1 : 0, m1 = p.r1 ? 1 : 0, m2 = p.r2 ? 1 : 0;
+                const int ldrb = p.rowbias ? p.ld_rowbias : 0, ld1 = p.r1 ? p.ld_r1 : 0, ld2 = p.r2 ? p.ld_r2 : 0;
+                constexpr int VPR = CP / 8;                 // 16-byte output vectors per row and pass
+                constexpr int ITERS = (16 * VPR + 63) / 64;  // 3 (the last one partial: 160 = 2*64 + 32)
+                auto is_live = [&](int it) { return it * 64 + lane < 16 * VPR; };
+                if constexpr ((EPI & ~1) == 0) {
+                    // No residual operands: bias / row-bias / SiLU / scale are applied in the ACCUMULATOR layout (4 consecutive
+                    // columns per lane: 8-byte operand loads of L2-resident vectors) and the result goes through the patch as
+                    // fp16 -- half the LDS bytes of the fp32 patch, no conversion after the read-back.  Same values, rounded
+                    // once, as the general path below.
+                    constexpr bool RB = EPI & 1;
+                    constexpr int NH = WN / CP;
+                    constexpr int LDH = CP + 8;              // patch row stride in halfs (176 B)
+                    f16* patch16 = (f16*)patch;
+                    const int rpg = p.rows_per_group;
+                    const bool silu = p.act == EW_ACT_SILU;
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+                        const int m_l = min(m_w0 + i * 16 + frow, p.M - 1);
+                        const int g = RB ? m_l / rpg : 0;
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) {
+#pragma unroll
+                            for (int jj = 0; jj < CP / 16; ++jj) {
+                                const int j = h * (CP / 16) + jj;
+                                const int n = n_w0 + j * 16 + fks * 4;
+                                const f16x4 b4 = *(const f16x4*)((const char*)bp + (unsigned)(n * mbias) * 2u);
+                                f32x4 x = acc[i][j] + (f32x4){(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
+                                if constexpr (RB) {
+                                    const f16x4 r4 = *(const f16x4*)((const char*)rbp + (unsigned)(g * ldrb + n * mrb) * 2u);
+                                    x += (f32x4){(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
+                                }
+                                if (silu) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) x[e] = ew_silu(x[e]);
+                                }
+                                x *= p.c_acc;
+                                const f16x4 o4 = {(f16)x[0], (f16)x[1], (f16)x[2], (f16)x[3]};
+                                *(f16x4*)(patch16 + frow * LDH + jj * 16 + fks * 4) = o4;
+                                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            }
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int it = 0; it < ITERS; ++it) {
+                                const int idx = it * 64 + lane;
+                                const int row = is_live(it) ? idx / VPR : 0, c8 = is_live(it) ? (idx - row * VPR) * 8 : 0;
+                                const int m = m_w0 + i * 16 + row, n = n_w0 + h * CP + c8;
+                                const f16x8 o = *(const f16x8*)(patch16 + row * LDH + c8);
+                                if (is_live(it) && (FULL || m < p.M) && !(p.dbg & 1)) *(f16x8*)((char*)p.out + (unsigned)(m * p.ld_out + n) * 2u) = o;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                } else if constexpr ((EPI & 8) == 0) {
+                    constexpr bool RB = EPI & 1, R1 = EPI & 2, R2 = EPI & 4;
+                    constexpr int NH = WN / CP;              // 2 column passes
+                    int rowv[ITERS], c8v[ITERS];
+#pragma unroll
+                    for (int it = 0; it < ITERS; ++it) {
+                        const int idx = it * 64 + lane;
+                        rowv[it] = is_live(it) ? idx / VPR : 0;
+                        c8v[it] = is_live(it) ? (idx - rowv[it] * VPR) * 8 : 0;
+                    }
+                    // vmcnt is in-order: a load issued after a store cannot be waited for without draining that store, so the
+                    // operands of store step s+1 are requested BEFORE the store of step s -- but AFTER step s has consumed
+                    // its own operands, into the same registers (one operand set: the 160 live accumulators leave no room
+                    // for two).
+                    f16x8 bvv, rbv, q1v, q2v;
+                    // row-bias group of a row: one boundary at most inside the wave's 64 rows when rows_per_group >= 64
+                    const int rpg = p.rows_per_group;
+                    const int g0 = m_w0 / rpg;
+                    const int gbound = rpg >= WM ? (g0 + 1) * rpg : 0x7fffffff;
+                    auto fetch = [&](int i, int h, int it) {
+                        const int m = m_w0 + i * 16 + rowv[it], n = n_w0 + h * CP + c8v[it];
+                        const int mc = FULL ? m : min(m, p.M - 1);
+                        // uniform base + 32-bit byte offset (every operand of this path is < 4 GB): one VGPR per address
+                        bvv = *(const f16x8*)((const char*)bp + (unsigned)(n * mbias) * 2u);
+                        if constexpr (RB) {
+                            const int g = rpg >= WM ? g0 + (mc >= gbound ? 1 : 0) : mc / rpg;
+                            rbv = *(const f16x8*)((const char*)rbp + (unsigned)(g * ldrb + n * mrb) * 2u);
+                        }
+                        if constexpr (R1) q1v = *(const f16x8*)((const char*)r1p + (unsigned)(mc * ld1 + n * m1) * 2u);
+                        if constexpr (R2) q2v = *(const f16x8*)((const char*)r2p + (unsigned)(mc * ld2 + n * m2) * 2u);
+                    };
+                    fetch(0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) {
+#pragma unroll
+                            for (int jj = 0; jj < CP / 16; ++jj) {
+                                *(f32x4*)(patch + frow * LDP + jj * 16 + fks * 4) = acc[i][h * (CP / 16) + jj];
+                                acc[i][h * (CP / 16) + jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            }
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int it = 0; it < ITERS; ++it) {
+                                const int row = rowv[it], c8 = c8v[it];
+                                const int m = m_w0 + i * 16 + row, n = n_w0 + h * CP + c8;
+                                const f32x4 lo = *(const f32x4*)(patch + row * LDP + c8);
+                                const f32x4 hi = *(const f32x4*)(patch + row * LDP + c8 + 4);
+                                float vv[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                                f16x8 o;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    vv[e] += (float)bvv[e];
+                                    if constexpr (RB) vv[e] += (float)rbv[e];
+                                }
+                                if (p.act == EW_ACT_SILU) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) vv[e] = ew_silu(vv[e]);
+                                }
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    float x = vv[e] * p.c_acc;
+                                    if constexpr (R1) x += p.c_r1 * (float)q1v[e];
+                                    if constexpr (R2) x += p.c_r2 * (float)q2v[e];
+                                    o[e] = (f16)x;
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (it + 1 < ITERS) fetch(i, h, it + 1);
+                                else if (h + 1 < NH) fetch(i, h + 1, 0);
+                                else if (i + 1 < FM) fetch(i + 1, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (is_live(it) && (FULL || m < p.M) && !(p.dbg & 1)) *(f16x8*)((char*)p.out + (unsigned)(m * p.ld_out + n) * 2u) = o;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                } else {
+                    // GEGLU: staged column blocks of 32 = [16 value | 16 gate] -> fragment 2q holds the values, 2q+1 the gates of
+                    // the SAME (row, column) positions in the SAME lane: value*gelu(gate) in registers, WN/2 = 80 output columns
+                    f32x4 bq[FN];
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        const f16x4 b4 = *(const f16x4*)(bp + (n_w0 + j * 16 + fks * 4) * mbias);
+                        bq[j] = (f32x4){(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
+                    }
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                        for (int q = 0; q < FN / 2; ++q) {
+                            const f32x4 va = acc[i][2 * q] + bq[2 * q], gg = acc[i][2 * q + 1] + bq[2 * q + 1];
+#ifdef EW_G3_NOGELU
+                            const f32x2 o01 = (f32x2){va[0], va[1]} * (f32x2){gg[0], gg[1]};        // measurement only: GELU cost
+                            const f32x2 o23 = (f32x2){va[2], va[3]} * (f32x2){gg[2], gg[3]};
+#else
+                            const f32x2 o01 = ew_vgelu2((f32x2){va[0], va[1]}, (f32x2){gg[0], gg[1]});
+                            const f32x2 o23 = ew_vgelu2((f32x2){va[2], va[3]}, (f32x2){gg[2], gg[3]});
+#endif
+                            const f16x4 o4 = {(f16)o01[0], (f16)o01[1], (f16)o23[0], (f16)o23[1]};
+                            *(f16x4*)((f16*)patch + frow * (CP + 8) + q * 16 + fks * 4) = o4;      // fp16 patch, row stride 176 B
+                            acc[i][2 * q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            acc[i][2 * q + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        }
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int it = 0; it < ITERS; ++it) {
+                            const int idx = it * 64 + lane;
+                            const int row = is_live(it) ? idx / VPR : 0, c8 = is_live(it) ? (idx - row * VPR) * 8 : 0;
+                            const int m = m_w0 + i * 16 + row;
+                            const f16x8 o = *(const f16x8*)((const f16*)patch + row * (CP + 8) + c8);
+                            const int no = (n_w0 >> 1) + c8;
+                            // non-temporal: the 4C-wide GEGLU output (1.2 GB at level 0) only evicts the operands from L2
+                            // (+5..6 % measured here; the same hint on the other epilogues measured -1..-18 %)
+                            if (is_live(it) && (FULL || m < p.M) && !(p.dbg & 1)) __builtin_nontemporal_store(o, (f16x8*)(p.out + (size_t)m * p.ld_out + no));
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            };
+            if (p.dbg & 2) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) { asm volatile("" :: "v"(acc[i][j])); acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            } else {
+                if (full) epilogue(std::true_type{}); else epilogue(std::false_type{});
+            }
+            sync();                                  // interval 5: the other group is in its last compute / its own epilogue
+        }
+    }
+    if (grp == 0) sync();                            // group 0 finished one interval early
+}
+
+template <int MODE, int EPI>
+ew_status launch4(const GemmP& p, hipStream_t s) {
+    GemmP q = p;
+    q.tiles_m = ew_cdiv(p.M, BM);
+    q.tiles_n = p.N / BN;
+    q.band = ((long long)p.N * p.K * 2 > 3LL * 1024 * 1024) ? 4 : 0;
+    const size_t lds = 2 * STAGE + 4 * PATCH_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm4_kernel<MODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { ew_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return EW_ERR_HIP; }
+        attr_set = true;
+    }
+    const long long tiles = (long long)q.tiles_m * q.tiles_n;
+    int grid = 256;                                   // persistent: one 8-wave workgroup per CU
+    if (tiles < grid) grid = (int)((tiles + 7) / 8 * 8);
+    snprintf(g_gemm_last_kernel, 64, "gemm4_kernel<%d, %d>", MODE, EPI);
+    hipLaunchKernelGGL((gemm4_kernel<MODE, EPI>), dim3(grid), dim3(64 * NW), lds, s, q);
+    return ew_check_launch("ew_gemm_f16(gen4)");
+}
+
+// operand sets that occur in the U-Net (evoworld_amd/unet.py); any other mask runs on the smallest compiled superset
+template <int MODE>
+ew_status dispatch_epi4(const GemmP& p, hipStream_t s) {
+    if (p.act == EW_ACT_GEGLU) {
+        if constexpr (MODE == EW_A_DENSE) return launch4<MODE, 8>(p, s);
+        else { ew_set_error("ew_gemm_f16: GEGLU epilogue is only built for dense mode"); return EW_ERR_UNSUPPORTED; }
+    }
+    if (p.rowbias) return launch4<MODE, 1>(p, s);
+    return launch4<MODE, 0>(p, s);
+}
+
+}  // namespace
+
+bool ew_gemm3_wants(const GemmP& p);
+// generation 4 takes what generation 3 takes, restricted to the operand sets with an fp16 patch (no residuals)
+bool ew_gemm4_wants(const GemmP& p) { return !p.r1 && !p.r2 && ew_gemm3_wants(p); }
+
+ew_status ew_gemm4_dispatch(const GemmP& p, hipStream_t s) {
+    if (p.mode == EW_A_CONV3X3) return dispatch_epi4<EW_A_CONV3X3>(p, s);
+    if (p.mode == EW_A_CONVT3) return dispatch_epi4<EW_A_CONVT3>(p, s);
+    return dispatch_epi4<EW_A_DENSE>(p, s);
+}
