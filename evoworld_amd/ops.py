@@ -86,11 +86,32 @@ def groupnorm_apply(x, sums, gamma, beta, y, n_slabs, rows, C_src, c_off, C_tot,
                "ew_groupnorm_apply_f16")
 
 
-def groupnorm(xs, gamma, beta, n_slabs, rows, eps, silu, groups=32, out=None):
+class SumsPool:
+    """Zero-initialised fp32 scratch for the GroupNorm statistics of one forward: ONE fill kernel per forward instead of one
+    per GroupNorm call (117 calls per U-Net forward).  `reset()` re-zeroes it; `take(n)` hands out the next n floats."""
+
+    def __init__(self, device, floats=1 << 20):
+        self.buf = torch.zeros(floats, dtype=torch.float32, device=device)
+        self.cur = 0
+
+    def reset(self):
+        if self.cur:
+            self.buf[: self.cur].zero_()
+        self.cur = 0
+
+    def take(self, n):
+        if self.cur + n > self.buf.numel():
+            return torch.zeros(n, dtype=torch.float32, device=self.buf.device)      # overflow: fall back to a fresh buffer
+        v = self.buf[self.cur: self.cur + n]
+        self.cur += n
+        return v
+
+
+def groupnorm(xs, gamma, beta, n_slabs, rows, eps, silu, groups=32, out=None, pool=None):
     """GroupNorm(+SiLU) over the channel concat of `xs` (list of [n_slabs*rows, C_i] fp16) -> [n_slabs*rows, sum C_i]."""
     C_tot = sum(x.shape[-1] for x in xs)
     dev = xs[0].device
-    sums = torch.zeros(n_slabs, groups, 2, dtype=torch.float32, device=dev)
+    sums = pool.take(n_slabs * groups * 2) if pool is not None else torch.zeros(n_slabs, groups, 2, dtype=torch.float32, device=dev)
     if out is None:
         out = torch.empty(n_slabs * rows, C_tot, dtype=torch.float16, device=dev)
     off = 0

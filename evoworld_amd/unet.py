@@ -397,10 +397,10 @@ class UNetSpatioTemporalConditionModel:
         x2 = xs[1] if len(xs) > 1 else None
         tb_s = tembs[:, self._temb_off[s]:]
         tb_t = tembs[:, self._temb_off[t]:]
-        hN = ops.groupnorm(xs, d["n1g"], d["n1b"], N, HW, r.eps, True)
+        hN = ops.groupnorm(xs, d["n1g"], d["n1b"], N, HW, r.eps, True, pool=self._gn_pool)
         h1 = self._conv3x3(hN, None, d["c1w"], d["c1b"], N, H, W_, H, W_, rowbias=tb_s, rows_per_group=T * HW,
                            ld_rowbias=self._temb_total)
-        h2 = ops.groupnorm([h1], d["n2g"], d["n2b"], N, HW, r.eps, True)
+        h2 = ops.groupnorm([h1], d["n2g"], d["n2b"], N, HW, r.eps, True, pool=self._gn_pool)
         if "scw" in d:
             sc = torch.empty(rows, r.cout, dtype=torch.float16, device=x1.device)
             c1 = x1.shape[-1]
@@ -409,10 +409,10 @@ class UNetSpatioTemporalConditionModel:
         else:
             sc = x1
         xsp = self._conv3x3(h2, None, d["c2w"], d["c2b"], N, H, W_, H, W_, r1=sc, ld_r1=r.cout)
-        g1 = ops.groupnorm([xsp], d["tn1g"], d["tn1b"], B, T * HW, r.eps, True)
+        g1 = ops.groupnorm([xsp], d["tn1g"], d["tn1b"], B, T * HW, r.eps, True, pool=self._gn_pool)
         t1 = self._convt(g1, d["t1w"], d["t1b"], B, T, HW, rowbias=tb_t, rows_per_group=T * HW,
                          ld_rowbias=self._temb_total)
-        g2 = ops.groupnorm([t1], d["tn2g"], d["tn2b"], B, T * HW, r.eps, True)
+        g2 = ops.groupnorm([t1], d["tn2g"], d["tn2b"], B, T * HW, r.eps, True, pool=self._gn_pool)
         # x_temporal = xsp + conv2(..); out = (1-a)*xsp + a*x_temporal with a = sigmoid(mix)  (switch_spatial_to_temporal_mix)
         return self._convt(g2, d["t2w"], d["t2b"], B, T, HW, r1=xsp, ld_r1=r.cout, c_acc=d["mix"], c_r1=1.0)
 
@@ -433,7 +433,7 @@ class UNetSpatioTemporalConditionModel:
         dev = x.device
         cv_s = cvecs[:, self._cv_off[(t.p, "s")]:]
         cv_t = cvecs[:, self._cv_off[(t.p, "t")]:]
-        hn = ops.groupnorm([x], d["ng"], d["nb"], N, S, 1e-6, False)
+        hn = ops.groupnorm([x], d["ng"], d["nb"], N, S, 1e-6, False, pool=self._gn_pool)
         h = ops.linear(hn, d["piw"], d["pib"])
         # --- spatial BasicTransformerBlock ---
         n1 = ops.layernorm(h, d["s_norm1g"], d["s_norm1b"])
@@ -474,6 +474,9 @@ class UNetSpatioTemporalConditionModel:
         """x: fp16 [B*T*H*W, 64] channels-last (18 real channels, zero padded) -> fp16 [B*T*H*W, 4]."""
         cfg, Wt = self._cfg, self.w
         dev = x.device
+        if getattr(self, "_gn_pool", None) is None or self._gn_pool.buf.device != dev:
+            self._gn_pool = ops.SumsPool(dev)
+        self._gn_pool.reset()
         boc = cfg["block_out_channels"]
         N = B * T
         ts = torch.as_tensor(timestep, dtype=torch.float32, device=dev).reshape(-1).expand(B)
@@ -525,7 +528,7 @@ class UNetSpatioTemporalConditionModel:
                 H, W_ = 2 * H, 2 * W_
             if taps is not None:
                 taps[f"up{bi}"] = (h, H, W_)
-        hn = ops.groupnorm([h], Wt["no_g"], Wt["no_b"], N, H * W_, 1e-5, True)
+        hn = ops.groupnorm([h], Wt["no_g"], Wt["no_b"], N, H * W_, 1e-5, True, pool=self._gn_pool)
         return self._conv3x3(hn, None, *Wt["conv_out"], N, H, W_, H, W_)
 
     @torch.no_grad()
