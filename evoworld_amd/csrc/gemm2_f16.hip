@@ -285,21 +285,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
             }
     };
 
-    if (p.dbg & 64) {
-        // Chip-wide phase staggering: persistent workgroups that start together stay in lock-step over the WHOLE chip (same
-        // tile shape, same duration), so HBM sees all 256 store-bound epilogues at once and idles during the MFMA phases.
-        // Spreading the start over one tile period makes the write traffic continuous.
-        const int period = nk * 20 + 48;                                  // in s_sleep(1) units of 64 cycles
-        const int mine = (int)(((blockIdx.x * 97u) & 255u) * (unsigned)period) >> 8;
-        for (int i = 0; i < mine; ++i) __builtin_amdgcn_s_sleep(1);
-    }
-    if constexpr (NW == 4 && BM < 256) {
-        // Two 4-wave workgroups share a CU.  Started together they stay in lock-step (same tile shape, same duration) and hit
-        // their store-bound epilogues at the same time; delaying the second half of the grid by ~half a tile makes one
-        // group's epilogue coincide with the other's MFMA phase.  (s_sleep 1 = 64 cycles; a K-tile is ~1300 cycles here.)
-        if ((p.dbg & 32) && blockIdx.x >= (gridDim.x >> 1))
-            for (int i = 0; i < nk * 10 + 16; ++i) __builtin_amdgcn_s_sleep(1);
-    }
     // ---------------- prologue: NSTAGE K-tiles requested, first fragments in registers ----------------
     // Ring rule: barrier(v) publishes stream position v+1 and frees slot v%NSTAGE; the DMA of position v+NSTAGE is issued
     // right after it -- except when position v ends an output tile: then the freed slot first hosts the epilogue patches
@@ -563,22 +548,15 @@ ew_status launch2(const GemmP& p, hipStream_t s) {
     return ew_check_launch("ew_gemm_f16(gen2)");
 }
 
-// Tile / workgroup shape.  variant 0 (default): 8-wave workgroups, 3-stage ring (256x160 | 128x256);
-// variant 1: 4-wave workgroups, 2 per CU, 2-stage ring (128x160 | 128x128) -- one group's epilogue (memory phase)
-// overlaps the other group's MFMA phase.  Selected by ew_set_gemm_debug bit 4 for A/B measurements.
+// Tile / workgroup shape: 8-wave workgroups, 3-stage ring, 256x160 where N is a multiple of 160, else (and for GEGLU) 128x256.
+// (Measured and dropped: 2 workgroups of 4 waves per CU with 128x160 / 128x128 tiles and a 2-stage ring, with and without a
+// start-phase offset; chip-wide start staggering; 4 waves x 512 VGPRs; a 256x256 / 2-stage GEGLU tile -- DESIGN.md 3.1.)
 template <int MODE, int EPI>
 ew_status dispatch_tile(const GemmP& p, hipStream_t s) {
-    const bool v1 = (p.dbg & 16) != 0;
     if constexpr (EPI & 8) {
-        if (v1) return launch2<128, 128, 2, 2, 2, MODE, EPI>(p, s);
-        // (a 256x256 / 2-stage GEGLU tile was measured 15-25 % slower: 41 spilled VGPRs, shallower ring)
         return launch2<128, 256, 2, 4, 3, MODE, EPI>(p, s);
     } else {
-        if (p.N % 160 == 0) {
-            if (v1) return launch2<256, 160, 2, 2, 3, MODE, EPI>(p, s);   // 4 waves x (128x80), one wave per SIMD, 512 VGPRs
-            return launch2<256, 160, 4, 2, 3, MODE, EPI>(p, s);
-        }
-        if (v1) return launch2<128, 128, 2, 2, 2, MODE, EPI>(p, s);
+        if (p.N % 160 == 0) return launch2<256, 160, 4, 2, 3, MODE, EPI>(p, s);
         return launch2<128, 256, 2, 4, 3, MODE, EPI>(p, s);
     }
 }
