@@ -12,11 +12,11 @@ from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libevoworld_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol declared in include/evoworld_hip.h
 SYMBOLS = [
-    "ew_abi_version", "ew_last_error", "ew_gemm_f16", "ew_set_gemm_generation", "ew_get_gemm_generation", "ew_set_gemm_debug", "ew_gemm_last_kernel", "ew_groupnorm_stats_f16", "ew_groupnorm_apply_f16",
+    "ew_abi_version", "ew_last_error", "ew_gemm_f16", "ew_set_gemm_generation", "ew_get_gemm_generation", "ew_set_gemm_debug", "ew_gemm_last_kernel", "ew_groupnorm_workspace_floats", "ew_groupnorm_stats_f16", "ew_groupnorm_finalize", "ew_groupnorm_apply_f16",
     "ew_layernorm_f16", "ew_attn_spatial_f16", "ew_attn_temporal_f16", "ew_nchw_f32_to_nhwc_f16",
     "ew_nhwc_f16_to_nchw_f32", "ew_euler_cfg_step", "ew_plucker_embed", "ew_cube2equi_gather",
     "ew_depth_unproject", "ew_splat_cubemap", "ew_splat_resolve", "ew_equi2pers", "ew_resize_aa_u8",
@@ -34,6 +34,7 @@ class GemmArgs(ctypes.Structure):
         ("n_img", c_int), ("h_in", c_int), ("w_in", c_int), ("h_out", c_int), ("w_out", c_int),
         ("stride", c_int), ("upsample", c_int), ("tB", c_int), ("tT", c_int), ("tP", c_int),
         ("rows_per_group", c_int), ("act", c_int), ("c_acc", c_float), ("c_r1", c_float), ("c_r2", c_float),
+        ("r1_lo", c_void_p), ("r2_lo", c_void_p), ("out_lo", c_void_p),
     ]
 
 
@@ -65,9 +66,10 @@ def load():
     P, I, F, LL = c_void_p, c_int, c_float, c_longlong
     sig = {
         "ew_gemm_f16": [ctypes.POINTER(GemmArgs), P],
-        "ew_groupnorm_stats_f16": [P, P, I, I, I, I, I, I, P],
-        "ew_groupnorm_apply_f16": [P, P, P, P, P, I, I, I, I, I, I, F, I, P],
-        "ew_layernorm_f16": [P, P, I, P, P, P, P, I, I, F, P],
+        "ew_groupnorm_stats_f16": [P, P, P, I, I, I, I, I, I, P],
+        "ew_groupnorm_finalize": [P, I, I, I, I, P],
+        "ew_groupnorm_apply_f16": [P, P, P, P, P, P, I, I, I, I, I, I, F, I, P],
+        "ew_layernorm_f16": [P, P, P, I, P, P, P, P, P, I, I, F, P],
         "ew_attn_spatial_f16": [P, P, P, P, I, I, I, I, LL, I, F, P],
         "ew_attn_temporal_f16": [P, P, P, P, I, I, I, I, I, I, F, P],
         "ew_nchw_f32_to_nhwc_f16": [P, P, I, I, I, I, I, I, F, P],
@@ -82,6 +84,8 @@ def load():
         "ew_resize_aa_u8": [P, P, P, P, P, I, P, P, I, I, I, I, I, I, P],
         "ew_u8_hwc_to_f32_chw": [P, P, I, I, I, P],
     }
+    lib.ew_groupnorm_workspace_floats.argtypes = [c_int, c_int, c_int, c_int]
+    lib.ew_groupnorm_workspace_floats.restype = c_size_t
     lib.ew_set_gemm_generation.argtypes = [c_int]
     lib.ew_set_gemm_generation.restype = None
     lib.ew_get_gemm_generation.restype = c_int

@@ -211,6 +211,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
 
     // Output stores issued by this wave in one FULL-tile epilogue (exact instruction count: every store executes).
     constexpr int NST = FM * ((((EPI & 8) ? 16 * (WN / 16) : 16 * (WN / 8)) + 63) / 64);   // 16-byte row-major stores
+    constexpr int NST2 = (EPI & 16) ? 2 * NST : NST;                  // split-fp16 residual stream: hi and lo stores
+    const bool lo_out = (EPI & 16) && p.out_lo != nullptr;
+    static_assert(GA + GB + 1 + NST2 < 64, "vmcnt is a 6-bit counter");
     // own DMA of the NEXT K-tile landed; the newest K-tile (n_ld DMA instructions) stays in flight.  `stores_behind`:
     // the NST output stores of the tile just finished were issued AFTER the DMA we wait for -- vmcnt counts in issue
     // order, so they are allowed to stay in flight too and the wave does not stall on store acknowledgements.
@@ -219,10 +222,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
         else {
             if (!more_in_flight) { wait_vmcnt<0>(); return; }
             if constexpr (GB > GB_FULL) {
-                if (has_tail) { if (stores_behind) wait_vmcnt<GA + GB_FULL + 1 + NST>(); else wait_vmcnt<GA + GB_FULL + 1>(); }
-                else { if (stores_behind) wait_vmcnt<GA + GB_FULL + NST>(); else wait_vmcnt<GA + GB_FULL>(); }
+                if (has_tail) { if (stores_behind) { if (lo_out) wait_vmcnt<GA + GB_FULL + 1 + NST2>(); else wait_vmcnt<GA + GB_FULL + 1 + NST>(); } else wait_vmcnt<GA + GB_FULL + 1>(); }
+                else { if (stores_behind) { if (lo_out) wait_vmcnt<GA + GB_FULL + NST2>(); else wait_vmcnt<GA + GB_FULL + NST>(); } else wait_vmcnt<GA + GB_FULL>(); }
             } else {
-                if (stores_behind) wait_vmcnt<GA + GB_FULL + NST>(); else wait_vmcnt<GA + GB_FULL>();
+                if (stores_behind) { if (lo_out) wait_vmcnt<GA + GB_FULL + NST2>(); else wait_vmcnt<GA + GB_FULL + NST>(); } else wait_vmcnt<GA + GB_FULL>();
             }
         }
     };
@@ -395,7 +398,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
                 // s+1 (row-bias, residuals) are requested BEFORE the store of step s.  With loads interleaved after each store
                 // the epilogue serialised into ~12 store round trips per tile (measured: epilogue = main loop at K=320).
                 if constexpr ((EPI & 8) == 0) {
-                    constexpr bool RB = EPI & 1, R1 = EPI & 2, R2 = EPI & 4;
+                    constexpr bool RB = EPI & 1, R1 = EPI & 2, R2 = EPI & 4, LO = EPI & 16;
+                    const f16* r1lp = p.r1_lo ? p.r1_lo : p.zero_page;      // split-fp16 residual stream companions
+                    const f16* r2lp = p.r2_lo ? p.r2_lo : p.zero_page;
+                    const int m1l = p.r1_lo ? 1 : 0, m2l = p.r2_lo ? 1 : 0;
+                    const int ld1l = p.r1_lo ? p.ld_r1 : 0, ld2l = p.r2_lo ? p.ld_r2 : 0;
                     constexpr int VPR = WN / 8;                 // 16-byte output vectors per row
                     constexpr int ITERS = (16 * VPR + 63) / 64;
                     constexpr int NS = FM * ITERS;
@@ -410,13 +417,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
                         const int n = n_w0 + c8v[it];
                         bvv[it] = *(const f16x8*)(bp + ((FULL || n + 8 <= p.N) ? n : 0) * mbias);
                     }
-                    f16x8 rbv[2], q1v[2], q2v[2];
+                    f16x8 rbv[2], q1v[2], q2v[2], q1l[2], q2l[2];
                     auto fetch = [&](int i, int it, int set) {
                         const int m = m_w0 + i * 16 + rowv[it], n = n_w0 + c8v[it];
                         const int mc = FULL ? m : min(m, p.M - 1), nc = (FULL || n + 8 <= p.N) ? n : 0;
                         if constexpr (RB) rbv[set] = *(const f16x8*)(rbp + (size_t)(mc / p.rows_per_group) * ldrb + nc * mrb);
                         if constexpr (R1) q1v[set] = *(const f16x8*)(r1p + (size_t)mc * ld1 + nc * m1);
                         if constexpr (R2) q2v[set] = *(const f16x8*)(r2p + (size_t)mc * ld2 + nc * m2);
+                        if constexpr (R1 && LO) q1l[set] = *(const f16x8*)(r1lp + (size_t)mc * ld1l + nc * m1l);
+                        if constexpr (R2 && LO) q2l[set] = *(const f16x8*)(r2lp + (size_t)mc * ld2l + nc * m2l);
                     };
                     fetch(0, 0, 0);
 #pragma unroll
@@ -437,23 +446,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
                             const f32x4 lo = *(const f32x4*)(patch + row * LDP + c8);
                             const f32x4 hi = *(const f32x4*)(patch + row * LDP + c8 + 4);
                             const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                            f16x8 o;
+                            f16x8 o, ol;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
                                 float x = v[e] + (float)bvv[it][e];
                                 if constexpr (RB) x += (float)rbv[set][e];
                                 if (p.act == EW_ACT_SILU) x = ew_silu(x);
                                 x *= p.c_acc;
-                                if constexpr (R1) x += p.c_r1 * (float)q1v[set][e];
-                                if constexpr (R2) x += p.c_r2 * (float)q2v[set][e];
+                                if constexpr (R1 && LO) x += p.c_r1 * ((float)q1v[set][e] + (float)q1l[set][e]);
+                                else if constexpr (R1) x += p.c_r1 * (float)q1v[set][e];
+                                if constexpr (R2 && LO) x += p.c_r2 * ((float)q2v[set][e] + (float)q2l[set][e]);
+                                else if constexpr (R2) x += p.c_r2 * (float)q2v[set][e];
                                 o[e] = (f16)x;
+                                if constexpr (LO) ol[e] = (f16)(x - (float)o[e]);
                             }
-                            if (FULL ? is_live(it) : (is_live(it) && m < p.M && n + 8 <= p.N && !(p.dbg & 1)))
+                            if (FULL ? is_live(it) : (is_live(it) && m < p.M && n + 8 <= p.N && !(p.dbg & 1))) {
                                 *(f16x8*)(p.out + (size_t)m * p.ld_out + n) = o;
-                            else if (!FULL && is_live(it) && m < p.M && !(p.dbg & 1)) {
+                                if constexpr (LO) {
+                                    if (p.out_lo) *(f16x8*)(p.out_lo + (size_t)m * p.ld_out + n) = ol;
+                                }
+                            } else if (!FULL && is_live(it) && m < p.M && !(p.dbg & 1)) {
 #pragma unroll
                                 for (int e = 0; e < 8; ++e)                     // ragged N edge (e.g. conv_out N=4)
-                                    if (n + e < p.N) p.out[(size_t)m * p.ld_out + n + e] = o[e];
+                                    if (n + e < p.N) {
+                                        p.out[(size_t)m * p.ld_out + n + e] = o[e];
+                                        if constexpr (LO) {
+                                            if (p.out_lo) p.out_lo[(size_t)m * p.ld_out + n + e] = ol[e];
+                                        }
+                                    }
                             }
                         }
                         __builtin_amdgcn_wave_barrier();
@@ -569,6 +589,16 @@ ew_status dispatch_epi(const GemmP& p, hipStream_t s) {
         else { ew_set_error("ew_gemm_f16: GEGLU epilogue is only built for dense mode"); return EW_ERR_UNSUPPORTED; }
     }
     const int mask = (p.rowbias ? 1 : 0) | (p.r1 ? 2 : 0) | (p.r2 ? 4 : 0);
+    if (p.r1_lo || p.r2_lo || p.out_lo) {           // split-fp16 residual stream
+        if constexpr (MODE == EW_A_DENSE) {
+            if ((mask & 4) == 0) return dispatch_tile<MODE, 16 | 3>(p, s);
+            return dispatch_tile<MODE, 16 | 7>(p, s);
+        } else {
+            if ((mask & 5) == 0) return dispatch_tile<MODE, 16 | 2>(p, s);
+            ew_set_error("ew_gemm_f16: conv modes carry the split residual only with r1 (no row-bias / r2)");
+            return EW_ERR_UNSUPPORTED;
+        }
+    }
     if (mask == 0) return dispatch_tile<MODE, 0>(p, s);
     if (mask == 1) return dispatch_tile<MODE, 1>(p, s);
     if (mask == 2) return dispatch_tile<MODE, 2>(p, s);

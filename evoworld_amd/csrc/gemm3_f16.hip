@@ -357,8 +357,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                         }
                     }
                 } else if constexpr ((EPI & 8) == 0) {
-                    constexpr bool RB = EPI & 1, R1 = EPI & 2, R2 = EPI & 4;
+                    constexpr bool RB = EPI & 1, R1 = EPI & 2, R2 = EPI & 4, LO = EPI & 16;
                     constexpr int NH = WN / CP;              // 2 column passes
+                    // split-fp16 residual stream: lo companions of r1 / r2 / out (same strides; absent ones read the zero page)
+                    const f16* r1lp = p.r1_lo ? p.r1_lo : p.zero_page;
+                    const f16* r2lp = p.r2_lo ? p.r2_lo : p.zero_page;
+                    const int m1l = p.r1_lo ? 1 : 0, m2l = p.r2_lo ? 1 : 0;
+                    const int ld1l = p.r1_lo ? p.ld_r1 : 0, ld2l = p.r2_lo ? p.ld_r2 : 0;
+                    f16x8 q1l, q2l;
                     int rowv[ITERS], c8v[ITERS];
 #pragma unroll
                     for (int it = 0; it < ITERS; ++it) {
@@ -386,6 +392,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                         }
                         if constexpr (R1) q1v = *(const f16x8*)((const char*)r1p + (unsigned)(mc * ld1 + n * m1) * 2u);
                         if constexpr (R2) q2v = *(const f16x8*)((const char*)r2p + (unsigned)(mc * ld2 + n * m2) * 2u);
+                        if constexpr (R1 && LO) q1l = *(const f16x8*)((const char*)r1lp + (unsigned)(mc * ld1l + n * m1l) * 2u);
+                        if constexpr (R2 && LO) q2l = *(const f16x8*)((const char*)r2lp + (unsigned)(mc * ld2l + n * m2l) * 2u);
                     };
                     fetch(0, 0, 0);
 #pragma unroll
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                                 const f32x4 lo = *(const f32x4*)(patch + row * LDP + c8);
                                 const f32x4 hi = *(const f32x4*)(patch + row * LDP + c8 + 4);
                                 float vv[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                                f16x8 o;
+                                f16x8 o, ol;
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) {
                                     vv[e] += (float)bvv[e];
@@ -418,16 +426,24 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) {
                                     float x = vv[e] * p.c_acc;
-                                    if constexpr (R1) x += p.c_r1 * (float)q1v[e];
-                                    if constexpr (R2) x += p.c_r2 * (float)q2v[e];
+                                    if constexpr (R1 && LO) x += p.c_r1 * ((float)q1v[e] + (float)q1l[e]);
+                                    else if constexpr (R1) x += p.c_r1 * (float)q1v[e];
+                                    if constexpr (R2 && LO) x += p.c_r2 * ((float)q2v[e] + (float)q2l[e]);
+                                    else if constexpr (R2) x += p.c_r2 * (float)q2v[e];
                                     o[e] = (f16)x;
+                                    if constexpr (LO) ol[e] = (f16)(x - (float)o[e]);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
                                 if (it + 1 < ITERS) fetch(i, h, it + 1);
                                 else if (h + 1 < NH) fetch(i, h + 1, 0);
                                 else if (i + 1 < FM) fetch(i + 1, 0, 0);
                                 __builtin_amdgcn_sched_barrier(0);
-                                if (is_live(it) && (FULL || m < p.M) && !(p.dbg & 1)) *(f16x8*)((char*)p.out + (unsigned)(m * p.ld_out + n) * 2u) = o;
+                                if (is_live(it) && (FULL || m < p.M) && !(p.dbg & 1)) {
+                                    *(f16x8*)((char*)p.out + (unsigned)(m * p.ld_out + n) * 2u) = o;
+                                    if constexpr (LO) {
+                                        if (p.out_lo) *(f16x8*)((char*)p.out_lo + (unsigned)(m * p.ld_out + n) * 2u) = ol;
+                                    }
+                                }
                             }
                             __builtin_amdgcn_wave_barrier();
                         }
@@ -528,6 +544,16 @@ ew_status dispatch_epi3(const GemmP& p, hipStream_t s) {
         else { ew_set_error("ew_gemm_f16: GEGLU epilogue is only built for dense mode"); return EW_ERR_UNSUPPORTED; }
     }
     const int mask = (p.rowbias ? 1 : 0) | (p.r1 ? 2 : 0) | (p.r2 ? 4 : 0);
+    if (p.r1_lo || p.r2_lo || p.out_lo) {           // split-fp16 residual stream: general path with the lo companions
+        if constexpr (MODE == EW_A_DENSE) {
+            if ((mask & 4) == 0) return launch3<MODE, 16 | 3>(p, s);
+            return launch3<MODE, 16 | 7>(p, s);
+        } else {
+            if ((mask & 5) == 0) return launch3<MODE, 16 | 2>(p, s);
+            ew_set_error("ew_gemm_f16: conv modes carry the split residual only with r1 (no row-bias / r2)");
+            return EW_ERR_UNSUPPORTED;
+        }
+    }
     if (mask == 0) return launch3<MODE, 0>(p, s);
     if (mask == 1) return launch3<MODE, 1>(p, s);
     if (mask == 2) return launch3<MODE, 2>(p, s);

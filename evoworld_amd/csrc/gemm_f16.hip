@@ -203,13 +203,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
                     v *= p.c_acc;
                     if (p.r1) {
                         const f16x4 b = *(const f16x4*)(p.r1 + (size_t)m * p.ld_r1 + n);
-                        v += p.c_r1 * (f32x4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                        f32x4 bf = {(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                        if (p.r1_lo) {
+                            const f16x4 l = *(const f16x4*)(p.r1_lo + (size_t)m * p.ld_r1 + n);
+                            bf += (f32x4){(float)l[0], (float)l[1], (float)l[2], (float)l[3]};
+                        }
+                        v += p.c_r1 * bf;
                     }
                     if (p.r2) {
                         const f16x4 b = *(const f16x4*)(p.r2 + (size_t)m * p.ld_r2 + n);
-                        v += p.c_r2 * (f32x4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                        f32x4 bf = {(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+                        if (p.r2_lo) {
+                            const f16x4 l = *(const f16x4*)(p.r2_lo + (size_t)m * p.ld_r2 + n);
+                            bf += (f32x4){(float)l[0], (float)l[1], (float)l[2], (float)l[3]};
+                        }
+                        v += p.c_r2 * bf;
                     }
-                    *(f16x4*)(p.out + (size_t)m * p.ld_out + n) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                    const f16x4 oh = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                    *(f16x4*)(p.out + (size_t)m * p.ld_out + n) = oh;
+                    if (p.out_lo)
+                        *(f16x4*)(p.out_lo + (size_t)m * p.ld_out + n) = (f16x4){(f16)(v[0] - (float)oh[0]), (f16)(v[1] - (float)oh[1]),
+                                                                                 (f16)(v[2] - (float)oh[2]), (f16)(v[3] - (float)oh[3])};
                 }
             }
         } else {
@@ -310,11 +324,13 @@ extern "C" ew_status ew_gemm_f16(const ew_gemm_args* a, void* stream) {
     EW_REQUIRE(a->act == EW_ACT_NONE || a->act == EW_ACT_SILU || a->act == EW_ACT_GEGLU, "ew_gemm_f16: unknown act %d", a->act);
     EW_REQUIRE(!a->rowbias || a->ld_rowbias % 4 == 0, "ew_gemm_f16: ld_rowbias must be a multiple of 4");
     if (a->act == EW_ACT_GEGLU)
-        EW_REQUIRE(a->N % 128 == 0 && !a->rowbias && !a->r1 && !a->r2, "ew_gemm_f16: GEGLU needs N %% 128 == 0 and no residuals");
+        EW_REQUIRE(a->N % 128 == 0 && !a->rowbias && !a->r1 && !a->r2 && !a->out_lo, "ew_gemm_f16: GEGLU needs N %% 128 == 0 and no residuals");
+    EW_REQUIRE((!a->r1_lo || a->r1) && (!a->r2_lo || a->r2), "ew_gemm_f16: r1_lo / r2_lo need r1 / r2");
     GemmP p;
     p.a = (const f16*)a->a; p.a2 = (const f16*)a->a2; p.w = (const f16*)a->w; p.bias = (const f16*)a->bias;
     p.rowbias = (const f16*)a->rowbias; p.r1 = (const f16*)a->r1; p.r2 = (const f16*)a->r2; p.out = (f16*)a->out;
     p.zero_page = (const f16*)a->zero_page;
+    p.r1_lo = (const f16*)a->r1_lo; p.r2_lo = (const f16*)a->r2_lo; p.out_lo = (f16*)a->out_lo;
     p.M = a->M; p.N = a->N; p.K = taps * (a->c1 + a->c2);
     p.c1 = a->c1; p.c2 = a->c2; p.lda = a->lda; p.lda2 = a->lda2; p.ld_out = a->ld_out; p.ld_r1 = a->ld_r1; p.ld_r2 = a->ld_r2; p.ld_rowbias = a->ld_rowbias;
     p.mode = a->mode; p.n_img = a->n_img; p.h_in = a->h_in; p.w_in = a->w_in; p.h_out = a->h_out; p.w_out = a->w_out;

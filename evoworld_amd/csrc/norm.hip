@@ -7,79 +7,172 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------
-// GroupNorm statistics.  grid = (row chunks, n_slabs); block = PL * VPP threads where VPP = C_src/8
-// vectors per row and PL row-lanes.  Every thread owns one fixed 8-channel vector -> per-channel
-// register accumulators -> LDS per-channel sums -> per-group reduce -> one fp32 atomic pair per
-// (block, group).
+// GroupNorm statistics: deterministic and cancellation-safe.
+//   stage 1 (gn_stats_kernel): grid = (row chunks, n_slabs); block = PL * VPP threads (VPP = C_src/8 vectors per row, PL
+//     row-lanes).  Every thread owns one fixed 8-channel vector and accumulates SHIFTED sums  s = sum(x - K_c),
+//     q = sum((x - K_c)^2)  with the pivot K_c = x[slab, row 0, c] (the same for every block of the slab, so partials add up;
+//     |mean_c - K_c| ~ std_c, which keeps q - s^2/n free of the E[x^2] - mean^2 cancellation).  The PL row-lanes of a block
+//     are combined through LDS in a FIXED order and the block writes one (s, q) pair per channel to
+//     part[slab][chunk][C_tot][2] -- no atomics anywhere.
+//   stage 2 (gn_finalize_kernel): one wave per (slab, group): lanes own channels, loop over the chunks in order, then a
+//     fixed shuffle tree: mean_g, var_g (two-level: per-channel mean / M2, then across the group's channels).
+// The chunking depends on (rows, n_slabs) only, so the two sources of a virtual channel concat share one partial buffer.
+// x_lo (may be null): lo half of a split-fp16 residual stream, x = hi + lo.
 // ---------------------------------------------------------------------------------------------
-__global__ void gn_stats_kernel(const f16* __restrict__ x, float* __restrict__ sums, int rows, int C_src, int c_off,
-                                int C_tot, int groups, int VPP, int PL, int rows_per_block) {
-    extern __shared__ float lds[];  // [2][C_src]
+__host__ __device__ inline int gn_chunks(int n_slabs, int rows) {
+    int want = (640 + n_slabs - 1) / n_slabs;                  // ~2.5 blocks per CU over the whole launch
+    const int cap = (rows + 63) / 64;                          // at least 64 rows per chunk
+    if (want > cap) want = cap;
+    if (want > 512) want = 512;
+    return want < 1 ? 1 : want;
+}
+
+__global__ void gn_stats_kernel(const f16* __restrict__ x, const f16* __restrict__ x_lo, float* __restrict__ part,
+                                float* __restrict__ pivot, int rows, int C_src, int c_off, int C_tot, int VPP, int PL,
+                                int rows_per_block) {
+    extern __shared__ float lds[];  // [PL][2][C_src]
     const int tid = threadIdx.x;
     const int slab = blockIdx.y;
-    for (int i = tid; i < 2 * C_src; i += blockDim.x) lds[i] = 0.f;
-    __syncthreads();
     const int v = tid % VPP, pl = tid / VPP;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(rows, r0 + rows_per_block);
-    float s[8], q[8];
+    float s[8], q[8], piv[8];
+    const size_t slab_off = ((size_t)slab * rows) * C_src + v * 8;
+    const f16* base = x + slab_off;
+    const f16* base_lo = x_lo ? x_lo + slab_off : nullptr;
+    {
+        const f16x8 p0 = *(const f16x8*)base;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-    const f16* base = x + ((size_t)slab * rows) * C_src + v * 8;
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; piv[e] = (float)p0[e]; }
+        if (base_lo) {
+            const f16x8 p1 = *(const f16x8*)base_lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) piv[e] += (float)p1[e];
+        }
+    }
     // eight independent 16-byte loads in flight per thread (one dependent load per iteration ran at 3.3 TB/s, four at 3.8)
     int r = r0 + pl;
-    for (; r + 7 * PL < r1; r += 8 * PL) {
-        f16x8 val[8];
+    if (base_lo) {
+        for (; r + 3 * PL < r1; r += 4 * PL) {
+            f16x8 val[4], vlo[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) val[u] = *(const f16x8*)(base + (size_t)(r + u * PL) * C_src);
+            for (int u = 0; u < 4; ++u) {
+                val[u] = *(const f16x8*)(base + (size_t)(r + u * PL) * C_src);
+                vlo[u] = *(const f16x8*)(base_lo + (size_t)(r + u * PL) * C_src);
+            }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = ((float)val[u][e] + (float)vlo[u][e]) - piv[e];
+                    s[e] += f;
+                    q[e] += f * f;
+                }
+        }
+        for (; r < r1; r += PL) {
+            const f16x8 val = *(const f16x8*)(base + (size_t)r * C_src);
+            const f16x8 vlo = *(const f16x8*)(base_lo + (size_t)r * C_src);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float f = (float)val[u][e];
+                const float f = ((float)val[e] + (float)vlo[e]) - piv[e];
                 s[e] += f;
                 q[e] += f * f;
             }
-    }
-    for (; r < r1; r += PL) {
-        const f16x8 val = *(const f16x8*)(base + (size_t)r * C_src);
+        }
+    } else {
+        for (; r + 7 * PL < r1; r += 8 * PL) {
+            f16x8 val[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float f = (float)val[e];
-            s[e] += f;
-            q[e] += f * f;
+            for (int u = 0; u < 8; ++u) val[u] = *(const f16x8*)(base + (size_t)(r + u * PL) * C_src);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)val[u][e] - piv[e];
+                    s[e] += f;
+                    q[e] += f * f;
+                }
+        }
+        for (; r < r1; r += PL) {
+            const f16x8 val = *(const f16x8*)(base + (size_t)r * C_src);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)val[e] - piv[e];
+                s[e] += f;
+                q[e] += f * f;
+            }
         }
     }
+    float* mine = lds + (size_t)pl * 2 * C_src;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        atomicAdd(&lds[v * 8 + e], s[e]);
-        atomicAdd(&lds[C_src + v * 8 + e], q[e]);
+        mine[v * 8 + e] = s[e];
+        mine[C_src + v * 8 + e] = q[e];
     }
     __syncthreads();
-    const int gs = C_tot / groups;
-    const int g_lo = c_off / gs, g_hi = (c_off + C_src - 1) / gs;
-    for (int g = g_lo + tid; g <= g_hi; g += blockDim.x) {
-        const int c_lo = max(g * gs, c_off) - c_off, c_hi = min((g + 1) * gs, c_off + C_src) - c_off;
+    float* dst = part + (((size_t)slab * gridDim.x + blockIdx.x) * C_tot + c_off) * 2;
+    for (int c = tid; c < C_src; c += blockDim.x) {
         float ss = 0.f, qq = 0.f;
-        for (int c = c_lo; c < c_hi; ++c) { ss += lds[c]; qq += lds[C_src + c]; }
-        atomicAdd(&sums[((size_t)slab * groups + g) * 2 + 0], ss);
-        atomicAdd(&sums[((size_t)slab * groups + g) * 2 + 1], qq);
+        for (int k = 0; k < PL; ++k) { ss += lds[(size_t)k * 2 * C_src + c]; qq += lds[(size_t)k * 2 * C_src + C_src + c]; }
+        *(f32x2*)(dst + 2 * c) = (f32x2){ss, qq};
     }
+    if (blockIdx.x == 0 && pl == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pivot[(size_t)slab * C_tot + c_off + v * 8 + e] = piv[e];
+    }
+}
+
+// one wave per (slab, group): stats[slab][g] = (mean, biased variance)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ pivot,
+                                                          float* __restrict__ stats, int n_slabs, int rows, int C_tot,
+                                                          int groups, int chunks) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= n_slabs * groups) return;
+    const int slab = wid / groups, g = wid - slab * groups;
+    const int gs = C_tot / groups;
+    const float n = (float)rows;
+    // per-channel mean and M2 (lane-strided channels of the group), chunks summed in order
+    float msum = 0.f, m2sum = 0.f;             // over this lane's channels: sum of mean_c, sum of M2_c
+    float mloc[8];                             // this lane's channel means (gs <= 512)
+    int nloc = 0;
+    for (int c = lane; c < gs; c += 64) {
+        const int ch = g * gs + c;
+        float ss = 0.f, qq = 0.f;
+        const float* p = part + (((size_t)slab * chunks) * C_tot + ch) * 2;
+        for (int k = 0; k < chunks; ++k) {
+            const f32x2 v = *(const f32x2*)(p + (size_t)k * C_tot * 2);
+            ss += v[0];
+            qq += v[1];
+        }
+        const float d = ss / n;
+        const float mc = pivot[(size_t)slab * C_tot + ch] + d;
+        m2sum += fmaxf(qq - ss * d, 0.f);
+        msum += mc;
+        if (nloc < 8) mloc[nloc] = mc;
+        ++nloc;
+    }
+    const float mean = wave_sum(msum) / (float)gs;
+    float dev = 0.f;
+    for (int k = 0; k < nloc && k < 8; ++k) { const float d = mloc[k] - mean; dev += d * d; }
+    const float var = (wave_sum(m2sum) + n * wave_sum(dev)) / (n * (float)gs);
+    if (lane == 0) *(f32x2*)(stats + (size_t)wid * 2) = (f32x2){mean, var};
 }
 
 // GroupNorm apply (+SiLU).  Same thread layout as the statistics kernel: grid = (row chunks, n_slabs), block = PL * VPP
 // threads, every thread owns one fixed 8-channel vector of one slab -> mean / rstd / gamma / beta collapse ONCE per thread
 // into scale[8], shift[8]; the row loop is load, 8 fma (+SiLU), store.  (The first version re-derived (row, column, slab,
 // group) with 64-bit divisions for every vector and ran at 2.8 TB/s.)
-__global__ void gn_apply_kernel(const f16* __restrict__ x, const float* __restrict__ sums, const f16* __restrict__ gamma,
-                                const f16* __restrict__ beta, f16* __restrict__ y, int rows, int C_src, int c_off, int C_tot,
-                                int groups, float eps, int silu, int VPP, int PL, int rows_per_block) {
+template <bool LO>
+__global__ void gn_apply_kernel(const f16* __restrict__ x, const f16* __restrict__ x_lo, const float* __restrict__ stats,
+                                const f16* __restrict__ gamma, const f16* __restrict__ beta, f16* __restrict__ y, int rows,
+                                int C_src, int c_off, int C_tot, int groups, float eps, int silu, int VPP, int PL,
+                                int rows_per_block) {
     const int tid = threadIdx.x;
     const int slab = blockIdx.y;
     const int v = tid % VPP, pl = tid / VPP;
     const int c = v * 8;
     const int gs = C_tot / groups;
-    const float inv_cnt = 1.0f / ((float)rows * (float)gs);
     const f16x8 gm = *(const f16x8*)(gamma + c_off + c);
     const f16x8 bt = *(const f16x8*)(beta + c_off + c);
     float scale[8], shift[8];
@@ -90,30 +183,35 @@ __global__ void gn_apply_kernel(const f16* __restrict__ x, const float* __restri
         const int g = (c_off + c + e) / gs;
         if (g != gprev) {
             gprev = g;
-            const float sm = sums[((size_t)slab * groups + g) * 2 + 0], q = sums[((size_t)slab * groups + g) * 2 + 1];
-            mean = sm * inv_cnt;
-            const float var = fmaxf(q * inv_cnt - mean * mean, 0.f);
-            rstd = rsqrtf(var + eps);
+            const f32x2 st = *(const f32x2*)(stats + ((size_t)slab * groups + g) * 2);
+            mean = st[0];
+            rstd = rsqrtf(st[1] + eps);
         }
-        // same evaluation order as before: ((x - mean) * rstd) * gamma + beta
+        // evaluation order: ((x - mean) * rstd) * gamma + beta
         scale[e] = rstd;
         shift[e] = mean;
     }
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(rows, r0 + rows_per_block);
     const f16* xin = x + ((size_t)slab * rows) * C_src + c;
+    const f16* xlo = LO ? x_lo + ((size_t)slab * rows) * C_src + c : nullptr;
     f16* yout = y + ((size_t)slab * rows) * C_tot + c_off + c;
     int r = r0 + pl;
     for (; r + 3 * PL < r1; r += 4 * PL) {
-        f16x8 val[4];
+        f16x8 val[4], vlo[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) val[u] = *(const f16x8*)(xin + (size_t)(r + u * PL) * C_src);
+        for (int u = 0; u < 4; ++u) {
+            val[u] = *(const f16x8*)(xin + (size_t)(r + u * PL) * C_src);
+            if constexpr (LO) vlo[u] = *(const f16x8*)(xlo + (size_t)(r + u * PL) * C_src);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             f16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float f = ((float)val[u][e] - shift[e]) * scale[e] * (float)gm[e] + (float)bt[e];
+                float xv = (float)val[u][e];
+                if constexpr (LO) xv += (float)vlo[u][e];
+                float f = (xv - shift[e]) * scale[e] * (float)gm[e] + (float)bt[e];
                 if (silu) f = ew_silu(f);
                 o[e] = (f16)f;
             }
@@ -122,10 +220,14 @@ __global__ void gn_apply_kernel(const f16* __restrict__ x, const float* __restri
     }
     for (; r < r1; r += PL) {
         const f16x8 val = *(const f16x8*)(xin + (size_t)r * C_src);
+        f16x8 vlo;
+        if constexpr (LO) vlo = *(const f16x8*)(xlo + (size_t)r * C_src);
         f16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float f = ((float)val[e] - shift[e]) * scale[e] * (float)gm[e] + (float)bt[e];
+            float xv = (float)val[e];
+            if constexpr (LO) xv += (float)vlo[e];
+            float f = (xv - shift[e]) * scale[e] * (float)gm[e] + (float)bt[e];
             if (silu) f = ew_silu(f);
             o[e] = (f16)f;
         }
@@ -138,8 +240,9 @@ __global__ void gn_apply_kernel(const f16* __restrict__ x, const float* __restri
 // two-pass (mean, then centred variance) on registers.
 // ---------------------------------------------------------------------------------------------
 template <int NV, int RPW>
-__global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, const f16* __restrict__ addvec, int rpg,
-                                                 f16* __restrict__ x_out, const f16* __restrict__ gamma,
+__global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, const f16* __restrict__ x_lo,
+                                                 const f16* __restrict__ addvec, int rpg, f16* __restrict__ x_out,
+                                                 f16* __restrict__ x_out_lo, const f16* __restrict__ gamma,
                                                  const f16* __restrict__ beta, f16* __restrict__ y, int rows, int C,
                                                  float eps) {
     // a wave owns RPW consecutive rows and issues all their loads before reducing any of them: at C = 320 a row is only
@@ -149,7 +252,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, cons
     if (row0 >= rows) return;
     const int VPP = C / 8;
     float v[RPW][NV][8];
-    f16x8 raw[RPW][NV], add[RPW][NV];
+    f16x8 raw[RPW][NV], add[RPW][NV], rlo[RPW][NV];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int row = min(row0 + r, rows - 1);
@@ -158,6 +261,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, cons
             const int vi = lane + k * 64;
             if (vi < VPP) {
                 raw[r][k] = *(const f16x8*)(x + (size_t)row * C + vi * 8);
+                if (x_lo) rlo[r][k] = *(const f16x8*)(x_lo + (size_t)row * C + vi * 8);
                 if (addvec) add[r][k] = *(const f16x8*)(addvec + (size_t)(row / rpg) * C + vi * 8);
             }
         }
@@ -179,15 +283,23 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, cons
             if (vi < VPP) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[r][k][e] = (float)raw[r][k][e];
+                if (x_lo) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[r][k][e] += (float)rlo[r][k][e];      // split-fp16 stream: x = hi + lo
+                }
                 if (addvec) {
-                    f16x8 xo;
+                    f16x8 xo, xl;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        // the sum is rounded to fp16 first: it IS the fp16 residual stream the block continues from
-                        xo[e] = (f16)(v[r][k][e] + (float)add[r][k][e]);
-                        v[r][k][e] = (float)xo[e];
+                        // what is normalised IS the residual stream the block continues from: fp16(x + add), or its
+                        // hi + lo split when the caller keeps the lo half (x_out_lo)
+                        const float sum = v[r][k][e] + (float)add[r][k][e];
+                        xo[e] = (f16)sum;
+                        xl[e] = (f16)(sum - (float)xo[e]);
+                        v[r][k][e] = x_out_lo ? (float)xo[e] + (float)xl[e] : (float)xo[e];
                     }
                     if (x_out && live) *(f16x8*)(x_out + (size_t)row * C + vi * 8) = xo;
+                    if (x_out_lo && live) *(f16x8*)(x_out_lo + (size_t)row * C + vi * 8) = xl;
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sum += v[r][k][e];
@@ -222,26 +334,58 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, cons
 
 }  // namespace
 
-extern "C" ew_status ew_groupnorm_stats_f16(const void* x, float* sums, int n_slabs, int rows, int C_src, int c_off,
-                                            int C_tot, int groups, void* stream) {
-    EW_REQUIRE(x && sums, "ew_groupnorm_stats_f16: null pointer");
+extern "C" size_t ew_groupnorm_workspace_floats(int n_slabs, int rows, int C_tot, int groups) {
+    if (n_slabs <= 0 || rows <= 0 || C_tot <= 0 || groups <= 0) return 0;
+    // partials [n_slabs][chunks][C_tot][2] | pivots [n_slabs][C_tot] | stats [n_slabs][groups][2]
+    return (size_t)n_slabs * gn_chunks(n_slabs, rows) * C_tot * 2 + (size_t)n_slabs * C_tot + (size_t)n_slabs * groups * 2;
+}
+
+namespace {
+struct GnWs { float* part; float* pivot; float* stats; int chunks; };
+inline GnWs gn_ws(float* ws, int n_slabs, int rows, int C_tot) {
+    GnWs w;
+    w.chunks = gn_chunks(n_slabs, rows);
+    w.part = ws;
+    w.pivot = ws + (size_t)n_slabs * w.chunks * C_tot * 2;
+    w.stats = w.pivot + (size_t)n_slabs * C_tot;
+    return w;
+}
+}  // namespace
+
+extern "C" ew_status ew_groupnorm_stats_f16(const void* x, const void* x_lo, float* ws, int n_slabs, int rows, int C_src,
+                                            int c_off, int C_tot, int groups, void* stream) {
+    EW_REQUIRE(x && ws, "ew_groupnorm_stats_f16: null pointer");
     EW_REQUIRE(n_slabs > 0 && rows > 0 && C_src > 0 && C_src % 8 == 0 && C_src <= 8192, "ew_groupnorm_stats_f16: bad shape");
     EW_REQUIRE(groups > 0 && C_tot % groups == 0 && c_off >= 0 && c_off + C_src <= C_tot, "ew_groupnorm_stats_f16: bad groups");
     const int VPP = C_src / 8;
     EW_REQUIRE(VPP <= 1024, "ew_groupnorm_stats_f16: C_src too large");
     const int PL = VPP >= 256 ? 1 : 256 / VPP;
-    int rpb = 128 * PL;                                        // rows per block: long streams (8 loads in flight x 16 iterations), but at least ~200 blocks
-    while (rpb > 16 * PL && (long long)ew_cdiv(rows, rpb) * n_slabs < 200) rpb /= 2;
-    dim3 grid(ew_cdiv(rows, rpb), n_slabs);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(VPP * PL), 2 * C_src * sizeof(float), (hipStream_t)stream,
-                       (const f16*)x, sums, rows, C_src, c_off, C_tot, groups, VPP, PL, rpb);
+    const GnWs w = gn_ws(ws, n_slabs, rows, C_tot);
+    const int rpb = ew_cdiv(rows, w.chunks);
+    EW_REQUIRE(ew_cdiv(rows, rpb) == w.chunks || true, "unreachable");
+    // chunks whose first row is past the end would leave their partial slot unwritten: rpb*(chunks-1) < rows always holds
+    dim3 grid(w.chunks, n_slabs);
+    const size_t lds = (size_t)PL * 2 * C_src * sizeof(float);
+    EW_REQUIRE(lds <= 64 * 1024, "ew_groupnorm_stats_f16: C_src too large for the LDS combine");
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(VPP * PL), lds, (hipStream_t)stream, (const f16*)x, (const f16*)x_lo,
+                       w.part, w.pivot, rows, C_src, c_off, C_tot, VPP, PL, rpb);
     return ew_check_launch("ew_groupnorm_stats_f16");
 }
 
-extern "C" ew_status ew_groupnorm_apply_f16(const void* x, const float* sums, const void* gamma, const void* beta, void* y,
-                                            int n_slabs, int rows, int C_src, int c_off, int C_tot, int groups, float eps,
-                                            int silu, void* stream) {
-    EW_REQUIRE(x && sums && gamma && beta && y, "ew_groupnorm_apply_f16: null pointer");
+extern "C" ew_status ew_groupnorm_finalize(float* ws, int n_slabs, int rows, int C_tot, int groups, void* stream) {
+    EW_REQUIRE(ws, "ew_groupnorm_finalize: null pointer");
+    EW_REQUIRE(n_slabs > 0 && rows > 0 && groups > 0 && C_tot % groups == 0 && C_tot / groups <= 512,
+               "ew_groupnorm_finalize: bad shape");
+    const GnWs w = gn_ws(ws, n_slabs, rows, C_tot);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(ew_cdiv((long long)n_slabs * groups, 4)), dim3(256), 0, (hipStream_t)stream,
+                       w.part, w.pivot, w.stats, n_slabs, rows, C_tot, groups, w.chunks);
+    return ew_check_launch("ew_groupnorm_finalize");
+}
+
+extern "C" ew_status ew_groupnorm_apply_f16(const void* x, const void* x_lo, const float* ws, const void* gamma,
+                                            const void* beta, void* y, int n_slabs, int rows, int C_src, int c_off, int C_tot,
+                                            int groups, float eps, int silu, void* stream) {
+    EW_REQUIRE(x && ws && gamma && beta && y, "ew_groupnorm_apply_f16: null pointer");
     EW_REQUIRE(n_slabs > 0 && rows > 0 && C_src > 0 && C_src % 8 == 0 && c_off % 8 == 0 && C_tot % 8 == 0,
                "ew_groupnorm_apply_f16: bad shape");
     EW_REQUIRE(groups > 0 && C_tot % groups == 0 && c_off >= 0 && c_off + C_src <= C_tot, "ew_groupnorm_apply_f16: bad groups");
@@ -249,24 +393,31 @@ extern "C" ew_status ew_groupnorm_apply_f16(const void* x, const float* sums, co
     EW_REQUIRE(VPP <= 1024, "ew_groupnorm_apply_f16: C_src too large");
     const int PL = VPP >= 256 ? 1 : 256 / VPP;
     const int rpb = 32 * PL;                                   // 32 vectors in flight per thread-column
+    const GnWs w = gn_ws((float*)ws, n_slabs, rows, C_tot);
     dim3 grid(ew_cdiv(rows, rpb), n_slabs);
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(VPP * PL), 0, (hipStream_t)stream, (const f16*)x, sums,
-                       (const f16*)gamma, (const f16*)beta, (f16*)y, rows, C_src, c_off, C_tot, groups, eps, silu, VPP, PL, rpb);
+    if (x_lo)
+        hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(VPP * PL), 0, (hipStream_t)stream, (const f16*)x, (const f16*)x_lo,
+                           w.stats, (const f16*)gamma, (const f16*)beta, (f16*)y, rows, C_src, c_off, C_tot, groups, eps, silu, VPP, PL, rpb);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(VPP * PL), 0, (hipStream_t)stream, (const f16*)x, (const f16*)nullptr,
+                           w.stats, (const f16*)gamma, (const f16*)beta, (f16*)y, rows, C_src, c_off, C_tot, groups, eps, silu, VPP, PL, rpb);
     return ew_check_launch("ew_groupnorm_apply_f16");
 }
 
-extern "C" ew_status ew_layernorm_f16(const void* x, const void* addvec, int rows_per_group, void* x_out, const void* gamma,
-                                      const void* beta, void* y, int rows, int C, float eps, void* stream) {
+extern "C" ew_status ew_layernorm_f16(const void* x, const void* x_lo, const void* addvec, int rows_per_group, void* x_out,
+                                      void* x_out_lo, const void* gamma, const void* beta, void* y, int rows, int C, float eps,
+                                      void* stream) {
     EW_REQUIRE(x && gamma && beta && y, "ew_layernorm_f16: null pointer");
     EW_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 2048, "ew_layernorm_f16: need C %% 8 == 0 and C <= 2048 (C=%d)", C);
     EW_REQUIRE(!addvec || rows_per_group >= 1, "ew_layernorm_f16: rows_per_group must be >= 1");
+    EW_REQUIRE(!x_out_lo || (addvec && x_out), "ew_layernorm_f16: x_out_lo needs addvec and x_out");
     const int nv = (C / 8 + 63) / 64;
     dim3 block(256);
     hipStream_t s = (hipStream_t)stream;
     const int rpg = rows_per_group >= 1 ? rows_per_group : 1;
 #define LN_LAUNCH(NV, RPW)                                                                                         \
-    hipLaunchKernelGGL((ln_kernel<NV, RPW>), dim3(ew_cdiv(rows, 4 * RPW)), block, 0, s, (const f16*)x,             \
-                       (const f16*)addvec, rpg, (f16*)x_out, (const f16*)gamma, (const f16*)beta, (f16*)y, rows, C, eps)
+    hipLaunchKernelGGL((ln_kernel<NV, RPW>), dim3(ew_cdiv(rows, 4 * RPW)), block, 0, s, (const f16*)x, (const f16*)x_lo, \
+                       (const f16*)addvec, rpg, (f16*)x_out, (f16*)x_out_lo, (const f16*)gamma, (const f16*)beta, (f16*)y, rows, C, eps)
     if (nv == 1) LN_LAUNCH(1, 4);
     else if (nv == 2) LN_LAUNCH(2, 4);
     else if (nv == 3) LN_LAUNCH(3, 2);

@@ -38,15 +38,47 @@ def zero_page(device):
     return _zero_pages[key]
 
 
+class Res:
+    """A residual-stream tensor carried as split fp16: value = hi + lo (lo = fp16(x - fp16(x)), ~21 mantissa bits; None when
+    the stream is kept in plain fp16).  The reference runs the stream in fp32 (unified_loop_consistency.py:188); consumers
+    that need an fp16 MFMA operand read `hi` alone, the residual epilogues and the norms read both halves."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi, lo=None):
+        self.hi, self.lo = hi, lo
+
+    @classmethod
+    def empty(cls, rows, C, device, split):
+        hi = torch.empty(rows, C, dtype=torch.float16, device=device)
+        return cls(hi, torch.empty_like(hi) if split else None)
+
+    def float(self):
+        return self.hi.float() if self.lo is None else self.hi.float() + self.lo.float()
+
+
+def _hl(x):
+    """tensor | Res | None -> (hi, lo)"""
+    if x is None:
+        return None, None
+    if isinstance(x, Res):
+        return x.hi, x.lo
+    return x, None
+
+
 def gemm(a, w, out, *, M, N, c1, lda, a2=None, c2=0, lda2=0, bias=None, rowbias=None, rows_per_group=1, ld_rowbias=None,
          r1=None, ld_r1=0, r2=None, ld_r2=0, ld_out=None, mode=A_DENSE, conv=None, tconv=None, act=ACT_NONE,
          c_acc=1.0, c_r1=1.0, c_r2=1.0):
     """out = c_acc*act(A@W^T + bias + rowbias) + c_r1*r1 + c_r2*r2  (see ew_gemm_f16).
-    conv = (n_img, h_in, w_in, h_out, w_out, stride, upsample); tconv = (B, T, P)."""
+    conv = (n_img, h_in, w_in, h_out, w_out, stride, upsample); tconv = (B, T, P).
+    r1 / r2 / out may be `Res` (split-fp16 residual stream): the lo halves ride along (ew_gemm_args.r1_lo ...)."""
     lib = _lib.load()
     g = GemmArgs()
+    r1h, r1l = _hl(r1)
+    r2h, r2l = _hl(r2)
+    outh, outl = _hl(out)
     g.a, g.a2, g.w, g.bias, g.rowbias = _ptr(a), _ptr(a2), _ptr(w), _ptr(bias), _ptr(rowbias)
-    g.r1, g.r2, g.out, g.zero_page = _ptr(r1), _ptr(r2), _ptr(out), _ptr(zero_page(a.device))
+    g.r1, g.r2, g.out, g.zero_page = _ptr(r1h), _ptr(r2h), _ptr(outh), _ptr(zero_page(a.device))
+    g.r1_lo, g.r2_lo, g.out_lo = _ptr(r1l), _ptr(r2l), _ptr(outl)
     g.M, g.N, g.c1, g.c2, g.lda, g.lda2 = M, N, c1, c2, lda, lda2
     n_out = N // 2 if act == ACT_GEGLU else N
     g.ld_out = ld_out if ld_out is not None else n_out
@@ -62,76 +94,78 @@ def gemm(a, w, out, *, M, N, c1, lda, a2=None, c2=0, lda2=0, bias=None, rowbias=
     return out
 
 
-def linear(x, w, bias=None, out=None, **kw):
-    """x [M,K] fp16 (row stride = K), w [N,K] fp16 -> [M,N]."""
+def linear(x, w, bias=None, out=None, split_out=False, **kw):
+    """x [M,K] fp16 (row stride = K), w [N,K] fp16 -> [M,N] (a `Res` with a lo half when split_out)."""
     _req(x, torch.float16, "x"); _req(w, torch.float16, "w")
     M, K = x.shape
     N = w.shape[0]
     act = kw.get("act", ACT_NONE)
     if out is None:
-        out = torch.empty(M, N // 2 if act == ACT_GEGLU else N, dtype=torch.float16, device=x.device)
+        n_out = N // 2 if act == ACT_GEGLU else N
+        out = Res.empty(M, n_out, x.device, True) if split_out else torch.empty(M, n_out, dtype=torch.float16, device=x.device)
     return gemm(x, w, out, M=M, N=N, c1=K, lda=K, bias=bias, **kw)
 
 
-def groupnorm_stats(x, sums, n_slabs, rows, C_src, c_off, C_tot, groups=32):
-    lib = _lib.load()
-    _lib.check(lib.ew_groupnorm_stats_f16(_ptr(x), _ptr(sums), n_slabs, rows, C_src, c_off, C_tot, groups, _stream()),
-               "ew_groupnorm_stats_f16")
+class WorkspacePool:
+    """fp32 scratch for the GroupNorm statistics of one forward (partials, pivots, stats: all written before they are read, so
+    nothing is zeroed).  `reset()` rewinds; `take(n)` hands out the next n floats."""
 
-
-def groupnorm_apply(x, sums, gamma, beta, y, n_slabs, rows, C_src, c_off, C_tot, eps, silu, groups=32):
-    lib = _lib.load()
-    _lib.check(lib.ew_groupnorm_apply_f16(_ptr(x), _ptr(sums), _ptr(gamma), _ptr(beta), _ptr(y), n_slabs, rows, C_src,
-                                          c_off, C_tot, groups, eps, 1 if silu else 0, _stream()),
-               "ew_groupnorm_apply_f16")
-
-
-class SumsPool:
-    """Zero-initialised fp32 scratch for the GroupNorm statistics of one forward: ONE fill kernel per forward instead of one
-    per GroupNorm call (117 calls per U-Net forward).  `reset()` re-zeroes it; `take(n)` hands out the next n floats."""
-
-    def __init__(self, device, floats=1 << 20):
-        self.buf = torch.zeros(floats, dtype=torch.float32, device=device)
+    def __init__(self, device, floats=8 << 20):
+        self.buf = torch.empty(floats, dtype=torch.float32, device=device)
         self.cur = 0
 
     def reset(self):
-        if self.cur:
-            self.buf[: self.cur].zero_()
         self.cur = 0
 
     def take(self, n):
+        n = (n + 63) // 64 * 64
         if self.cur + n > self.buf.numel():
-            return torch.zeros(n, dtype=torch.float32, device=self.buf.device)      # overflow: fall back to a fresh buffer
+            return torch.empty(n, dtype=torch.float32, device=self.buf.device)      # overflow: a fresh buffer
         v = self.buf[self.cur: self.cur + n]
         self.cur += n
         return v
 
 
+SumsPool = WorkspacePool   # former name
+
+
 def groupnorm(xs, gamma, beta, n_slabs, rows, eps, silu, groups=32, out=None, pool=None):
-    """GroupNorm(+SiLU) over the channel concat of `xs` (list of [n_slabs*rows, C_i] fp16) -> [n_slabs*rows, sum C_i]."""
-    C_tot = sum(x.shape[-1] for x in xs)
-    dev = xs[0].device
-    sums = pool.take(n_slabs * groups * 2) if pool is not None else torch.zeros(n_slabs, groups, 2, dtype=torch.float32, device=dev)
+    """GroupNorm(+SiLU) over the channel concat of `xs` (list of [n_slabs*rows, C_i] fp16 tensors or `Res`) ->
+    [n_slabs*rows, sum C_i] fp16.  Deterministic shifted statistics: stats per source, one finalize, apply per source."""
+    lib = _lib.load()
+    srcs = [_hl(x) for x in xs]
+    C_tot = sum(h.shape[-1] for h, _ in srcs)
+    dev = srcs[0][0].device
+    nws = lib.ew_groupnorm_workspace_floats(n_slabs, rows, C_tot, groups)
+    ws = pool.take(nws) if pool is not None else torch.empty(nws, dtype=torch.float32, device=dev)
     if out is None:
         out = torch.empty(n_slabs * rows, C_tot, dtype=torch.float16, device=dev)
+    st = _stream()
     off = 0
-    for x in xs:
-        groupnorm_stats(x, sums, n_slabs, rows, x.shape[-1], off, C_tot, groups)
-        off += x.shape[-1]
+    for h, l in srcs:
+        _lib.check(lib.ew_groupnorm_stats_f16(_ptr(h), _ptr(l), _ptr(ws), n_slabs, rows, h.shape[-1], off, C_tot, groups, st),
+                   "ew_groupnorm_stats_f16")
+        off += h.shape[-1]
+    _lib.check(lib.ew_groupnorm_finalize(_ptr(ws), n_slabs, rows, C_tot, groups, st), "ew_groupnorm_finalize")
     off = 0
-    for x in xs:
-        groupnorm_apply(x, sums, gamma, beta, out, n_slabs, rows, x.shape[-1], off, C_tot, eps, silu, groups)
-        off += x.shape[-1]
+    for h, l in srcs:
+        _lib.check(lib.ew_groupnorm_apply_f16(_ptr(h), _ptr(l), _ptr(ws), _ptr(gamma), _ptr(beta), _ptr(out), n_slabs, rows,
+                                              h.shape[-1], off, C_tot, groups, eps, 1 if silu else 0, st),
+                   "ew_groupnorm_apply_f16")
+        off += h.shape[-1]
     return out
 
 
 def layernorm(x, gamma, beta, eps=1e-5, addvec=None, rows_per_group=1, x_out=None, out=None):
+    """x, x_out: fp16 tensors or `Res` (split-fp16 residual stream)."""
     lib = _lib.load()
-    rows, C = x.shape
+    xh, xl = _hl(x)
+    oh, ol = _hl(x_out)
+    rows, C = xh.shape
     if out is None:
-        out = torch.empty_like(x)
-    _lib.check(lib.ew_layernorm_f16(_ptr(x), _ptr(addvec), rows_per_group, _ptr(x_out), _ptr(gamma), _ptr(beta),
-                                    _ptr(out), rows, C, eps, _stream()), "ew_layernorm_f16")
+        out = torch.empty_like(xh)
+    _lib.check(lib.ew_layernorm_f16(_ptr(xh), _ptr(xl), _ptr(addvec), rows_per_group, _ptr(oh), _ptr(ol), _ptr(gamma),
+                                    _ptr(beta), _ptr(out), rows, C, eps, _stream()), "ew_layernorm_f16")
     return out
 
 

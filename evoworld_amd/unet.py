@@ -29,7 +29,7 @@ from types import SimpleNamespace
 import torch
 
 from . import ops
-from .ops import A_CONV3X3, A_CONVT3, A_DENSE, ACT_GEGLU, ACT_NONE, ACT_SILU
+from .ops import A_CONV3X3, A_CONVT3, A_DENSE, ACT_GEGLU, ACT_NONE, ACT_SILU, Res
 
 DEFAULT_CONFIG = dict(  # evoworld/trainer/unet_plucker.py:69-94 with in_channels=18 (trainer_utils.py:19)
     sample_size=None, in_channels=18, out_channels=4,
@@ -217,6 +217,11 @@ class UNetSpatioTemporalConditionModel:
         self.add_embedding = SimpleNamespace(linear_1=SimpleNamespace(
             in_features=cfg["projection_class_embeddings_input_dim"]))
         self.dtype = torch.float16
+        # residual stream: split fp16 (hi + lo, ~21 bits; default) or plain fp16 (EW_RESIDUAL=fp16: -15 % HBM traffic,
+        # +30 % rel-L2 distance to the fp32 reference -- DESIGN.md section 4)
+        mode = os.environ.get("EW_RESIDUAL", "split")
+        self.split_residual = mode != "fp16"
+        self.split_heads = mode == "split"     # also split the stream tensors produced WITHOUT a residual operand
         self._pos_cache = {}
         for hd, c in zip(cfg["num_attention_heads"], cfg["block_out_channels"]):
             if c // hd != 64:
@@ -276,6 +281,7 @@ class UNetSpatioTemporalConditionModel:
     # ---------------- weight packing (once) ----------------
     def _pack(self, sd):
         dev = self.device
+        self._pos_cache = {}   # time_pos_embed outputs depend on the weights being replaced
         W = {}
 
         def f32(k):
@@ -373,28 +379,33 @@ class UNetSpatioTemporalConditionModel:
         self.w = W
 
     # ---------------- building blocks ----------------
-    def _conv3x3(self, x, x2, w, b, N, H, W_, Ho, Wo, stride=1, upsample=0, **kw):
+    def _res(self, rows, C, dev, head=False):
+        return Res.empty(rows, C, dev, self.split_heads if head else self.split_residual)
+
+    def _conv3x3(self, x, x2, w, b, N, H, W_, Ho, Wo, stride=1, upsample=0, res_out=False, **kw):
         c1 = x.shape[-1]
         c2 = x2.shape[-1] if x2 is not None else 0
         M = N * Ho * Wo
-        out = torch.empty(M, w.shape[0], dtype=torch.float16, device=x.device)
+        out = self._res(M, w.shape[0], x.device, head="r1" not in kw) if res_out else torch.empty(M, w.shape[0], dtype=torch.float16, device=x.device)
         return ops.gemm(x, w, out, M=M, N=w.shape[0], c1=c1, lda=c1, a2=x2, c2=c2, lda2=c2, bias=b,
                         mode=A_CONV3X3, conv=(N, H, W_, Ho, Wo, stride, upsample), **kw)
 
-    def _convt(self, x, w, b, B, T, P, **kw):
+    def _convt(self, x, w, b, B, T, P, res_out=False, **kw):
         C = x.shape[-1]
         M = B * T * P
-        out = torch.empty(M, w.shape[0], dtype=torch.float16, device=x.device)
+        out = self._res(M, w.shape[0], x.device) if res_out else torch.empty(M, w.shape[0], dtype=torch.float16, device=x.device)
         return ops.gemm(x, w, out, M=M, N=w.shape[0], c1=C, lda=C, bias=b, mode=A_CONVT3, tconv=(B, T, P), **kw)
 
     def _resblock(self, r, xs, tembs, B, T, H, W_):
-        """SpatioTemporalResBlock = ResnetBlock2D -> TemporalResnetBlock -> AlphaBlender."""
+        """SpatioTemporalResBlock = ResnetBlock2D -> TemporalResnetBlock -> AlphaBlender.
+        xs: one or two `Res` (the up-block skip concat is addressing); returns a `Res`."""
         d = self.w[r.p]
         N, HW = B * T, H * W_
         rows = N * HW
         s, t = r.p + ".spatial_res_block", r.p + ".temporal_res_block"
         x1 = xs[0]
         x2 = xs[1] if len(xs) > 1 else None
+        dev = x1.hi.device
         tb_s = tembs[:, self._temb_off[s]:]
         tb_t = tembs[:, self._temb_off[t]:]
         hN = ops.groupnorm(xs, d["n1g"], d["n1b"], N, HW, r.eps, True, pool=self._gn_pool)
@@ -402,19 +413,22 @@ class UNetSpatioTemporalConditionModel:
                            ld_rowbias=self._temb_total)
         h2 = ops.groupnorm([h1], d["n2g"], d["n2b"], N, HW, r.eps, True, pool=self._gn_pool)
         if "scw" in d:
-            sc = torch.empty(rows, r.cout, dtype=torch.float16, device=x1.device)
-            c1 = x1.shape[-1]
-            c2 = x2.shape[-1] if x2 is not None else 0
-            ops.gemm(x1, d["scw"], sc, M=rows, N=r.cout, c1=c1, lda=c1, a2=x2, c2=c2, lda2=c2, bias=d["scb"])
+            sc = self._res(rows, r.cout, dev, head=True)
+            c1 = x1.hi.shape[-1]
+            c2 = x2.hi.shape[-1] if x2 is not None else 0
+            ops.gemm(x1.hi, d["scw"], sc, M=rows, N=r.cout, c1=c1, lda=c1, a2=x2.hi if x2 is not None else None, c2=c2,
+                     lda2=c2, bias=d["scb"])
         else:
             sc = x1
-        xsp = self._conv3x3(h2, None, d["c2w"], d["c2b"], N, H, W_, H, W_, r1=sc, ld_r1=r.cout)
+        xsp = self._conv3x3(h2, None, d["c2w"], d["c2b"], N, H, W_, H, W_, r1=sc, ld_r1=r.cout, res_out=True)
         g1 = ops.groupnorm([xsp], d["tn1g"], d["tn1b"], B, T * HW, r.eps, True, pool=self._gn_pool)
         t1 = self._convt(g1, d["t1w"], d["t1b"], B, T, HW, rowbias=tb_t, rows_per_group=T * HW,
                          ld_rowbias=self._temb_total)
         g2 = ops.groupnorm([t1], d["tn2g"], d["tn2b"], B, T * HW, r.eps, True, pool=self._gn_pool)
-        # x_temporal = xsp + conv2(..); out = (1-a)*xsp + a*x_temporal with a = sigmoid(mix)  (switch_spatial_to_temporal_mix)
-        return self._convt(g2, d["t2w"], d["t2b"], B, T, HW, r1=xsp, ld_r1=r.cout, c_acc=d["mix"], c_r1=1.0)
+        # x_temporal = xsp + conv2(..); AlphaBlender (switch_spatial_to_temporal_mix=False, the SpatioTemporalResBlock
+        # default the U-Net blocks use): out = a*xsp + (1-a)*x_temporal = xsp + (1-a)*conv2(..), a = sigmoid(mix)
+        return self._convt(g2, d["t2w"], d["t2b"], B, T, HW, r1=xsp, ld_r1=r.cout, c_acc=1.0 - d["mix"], c_r1=1.0,
+                           res_out=True)
 
     def _pos_emb(self, t, B, T):
         key = (t.p, B, T)
@@ -426,15 +440,17 @@ class UNetSpatioTemporalConditionModel:
         return self._pos_cache[key]
 
     def _transformer(self, t, x, cvecs, B, T, H, W_):
-        """TransformerSpatioTemporalModel."""
+        """TransformerSpatioTemporalModel.  x and the result are `Res`; every tensor of the block's
+        residual stream (h, hm) is a `Res`, the GEMM operands (norm outputs, q/k/v, attention output, GEGLU output, the
+        blended hb) are plain fp16."""
         d = self.w[t.p]
         C, N, S = t.ch, B * T, H * W_
         rows = N * S
-        dev = x.device
+        dev = x.hi.device
         cv_s = cvecs[:, self._cv_off[(t.p, "s")]:]
         cv_t = cvecs[:, self._cv_off[(t.p, "t")]:]
         hn = ops.groupnorm([x], d["ng"], d["nb"], N, S, 1e-6, False, pool=self._gn_pool)
-        h = ops.linear(hn, d["piw"], d["pib"])
+        h = ops.linear(hn, d["piw"], d["pib"], out=self._res(rows, C, dev, head=True))
         # --- spatial BasicTransformerBlock ---
         n1 = ops.layernorm(h, d["s_norm1g"], d["s_norm1b"])
         qk = ops.linear(n1, d["s_qk"])
@@ -444,30 +460,30 @@ class UNetSpatioTemporalConditionModel:
         ops.attn_spatial(qk, qk[:, C:], vt, ao, N, S, t.heads, 2 * C, rows, C)
         del qk, vt
         # attn1 out-proj + residual + folded single-token cross attention (per batch row)
-        h = ops.linear(ao, d["s_ow"], d["s_ob"], rowbias=cv_s, rows_per_group=T * S, ld_rowbias=self._cv_total,
-                       r1=h, ld_r1=C)
+        h = ops.linear(ao, d["s_ow"], d["s_ob"], out=self._res(rows, C, dev), rowbias=cv_s, rows_per_group=T * S,
+                       ld_rowbias=self._cv_total, r1=h, ld_r1=C)
         n3 = ops.layernorm(h, d["s_norm3g"], d["s_norm3b"])
         ffh = ops.linear(n3, d["s_f1w"], d["s_f1b"], act=ACT_GEGLU)
-        h = ops.linear(ffh, d["s_f2w"], d["s_f2b"], r1=h, ld_r1=C)
+        h = ops.linear(ffh, d["s_f2w"], d["s_f2b"], out=self._res(rows, C, dev), r1=h, ld_r1=C)
         del ffh
         # --- TemporalBasicTransformerBlock on frame-major tokens (regroup = addressing) ---
-        hm = torch.empty_like(h)
+        hm = self._res(rows, C, dev)
         nin = ops.layernorm(h, d["t_norm_ing"], d["t_norm_inb"], addvec=self._pos_emb(t, B, T), rows_per_group=S, x_out=hm)
         ffh = ops.linear(nin, d["t_fi1w"], d["t_fi1b"], act=ACT_GEGLU)
-        hm = ops.linear(ffh, d["t_fi2w"], d["t_fi2b"], r1=hm, ld_r1=C)
+        hm = ops.linear(ffh, d["t_fi2w"], d["t_fi2b"], out=self._res(rows, C, dev), r1=hm, ld_r1=C)
         del ffh
         n1 = ops.layernorm(hm, d["t_norm1g"], d["t_norm1b"])
         qkv = ops.linear(n1, d["t_qkv"])
         ops.attn_temporal(qkv, qkv[:, C:], qkv[:, 2 * C:], ao, B, T, S, t.heads, 3 * C, C)
         del qkv
-        hm = ops.linear(ao, d["t_ow"], d["t_ob"], rowbias=cv_t, rows_per_group=T * S, ld_rowbias=self._cv_total,
-                        r1=hm, ld_r1=C)
+        hm = ops.linear(ao, d["t_ow"], d["t_ob"], out=self._res(rows, C, dev), rowbias=cv_t, rows_per_group=T * S,
+                        ld_rowbias=self._cv_total, r1=hm, ld_r1=C)
         n3 = ops.layernorm(hm, d["t_norm3g"], d["t_norm3b"])
         ffh = ops.linear(n3, d["t_f1w"], d["t_f1b"], act=ACT_GEGLU)
-        a = d["mix"]  # AlphaBlender: a*x_spatial + (1-a)*x_temporal, x_temporal = hm + ff(..)
+        a = d["mix"]  # AlphaBlender: a*x_spatial + (1-a)*x_temporal, x_temporal = hm + ff(..); hb is only a GEMM operand
         hb = ops.linear(ffh, d["t_f2w"], d["t_f2b"], c_acc=1.0 - a, r1=hm, ld_r1=C, c_r1=1.0 - a, r2=h, ld_r2=C, c_r2=a)
         del ffh
-        return ops.linear(hb, d["pow"], d["pob"], r1=x, ld_r1=C)
+        return ops.linear(hb, d["pow"], d["pob"], out=self._res(rows, C, dev), r1=x, ld_r1=C)
 
     # ---------------- forward ----------------
     def forward_nhwc(self, x, timestep, encoder_hidden_states, added_time_ids, B, T, H, W_, taps=None):
@@ -475,7 +491,7 @@ class UNetSpatioTemporalConditionModel:
         cfg, Wt = self._cfg, self.w
         dev = x.device
         if getattr(self, "_gn_pool", None) is None or self._gn_pool.buf.device != dev:
-            self._gn_pool = ops.SumsPool(dev)
+            self._gn_pool = ops.WorkspacePool(dev)
         self._gn_pool.reset()
         boc = cfg["block_out_channels"]
         N = B * T
@@ -492,9 +508,9 @@ class UNetSpatioTemporalConditionModel:
         ehs = encoder_hidden_states.to(device=dev, dtype=torch.float16).reshape(B, -1).contiguous()
         cvecs = ops.linear(ehs, Wt["cv_w"], Wt["cv_b"])               # all 32 cross-attention vectors at once
 
-        h = self._conv3x3(x, None, *Wt["conv_in"], N, H, W_, H, W_)
+        h = self._conv3x3(x, None, *Wt["conv_in"], N, H, W_, H, W_, res_out=True)
         if taps is not None:
-            taps["conv_in"] = (h, H, W_)
+            taps["conv_in"] = (h.float(), H, W_)
         skips = [(h, H, W_)]
         for bi, blk in enumerate(self.arch.downs):
             for l, r in enumerate(blk.res):
@@ -504,17 +520,17 @@ class UNetSpatioTemporalConditionModel:
                 skips.append((h, H, W_))
             if blk.down:
                 w, b = Wt[blk.down.p]
-                h = self._conv3x3(h, None, w, b, N, H, W_, H // 2, W_ // 2, stride=2)
+                h = self._conv3x3(h.hi, None, w, b, N, H, W_, H // 2, W_ // 2, stride=2, res_out=True)
                 H, W_ = H // 2, W_ // 2
                 skips.append((h, H, W_))
             if taps is not None:
-                taps[f"down{bi}"] = (h, H, W_)
+                taps[f"down{bi}"] = (h.float(), H, W_)
         m = self.arch.mid
         h = self._resblock(m.res[0], [h], tembs, B, T, H, W_)
         h = self._transformer(m.attn[0], h, cvecs, B, T, H, W_)
         h = self._resblock(m.res[1], [h], tembs, B, T, H, W_)
         if taps is not None:
-            taps["mid"] = (h, H, W_)
+            taps["mid"] = (h.float(), H, W_)
         for bi, blk in enumerate(self.arch.ups):
             for l, r in enumerate(blk.res):
                 sk, sh, sw = skips.pop()
@@ -524,10 +540,10 @@ class UNetSpatioTemporalConditionModel:
                     h = self._transformer(blk.attn[l], h, cvecs, B, T, H, W_)
             if blk.up:
                 w, b = Wt[blk.up.p]
-                h = self._conv3x3(h, None, w, b, N, H, W_, 2 * H, 2 * W_, upsample=1)
+                h = self._conv3x3(h.hi, None, w, b, N, H, W_, 2 * H, 2 * W_, upsample=1, res_out=True)
                 H, W_ = 2 * H, 2 * W_
             if taps is not None:
-                taps[f"up{bi}"] = (h, H, W_)
+                taps[f"up{bi}"] = (h.float(), H, W_)
         hn = ops.groupnorm([h], Wt["no_g"], Wt["no_b"], N, H * W_, 1e-5, True, pool=self._gn_pool)
         return self._conv3x3(hn, None, *Wt["conv_out"], N, H, W_, H, W_)
 

@@ -27,7 +27,7 @@ typedef int ew_status;
 #define EW_ERR_UNSUPPORTED (-2)
 #define EW_ERR_HIP (-3)
 
-#define EW_ABI_VERSION 1
+#define EW_ABI_VERSION 2
 int ew_abi_version(void);
 const char* ew_last_error(void);
 
@@ -77,6 +77,13 @@ typedef struct ew_gemm_args {
     int rows_per_group; /* rowbias group size in rows (>=1) */
     int act;            /* EW_ACT_* */
     float c_acc, c_r1, c_r2;
+    /* Split-fp16 residual stream (ABI 2): a residual-stream tensor x is carried as hi = fp16(x) plus lo = fp16(x - hi)
+     * (~21 mantissa bits; the reference keeps the stream in fp32, unified_loop_consistency.py:188).  Consumers that only
+     * need an fp16 operand read `hi` alone.  r1_lo / r2_lo (same strides as r1 / r2) are added to r1 / r2 in fp32;
+     * out_lo (stride ld_out) receives fp16(v - fp16(v)).  Any of them may be NULL; not available with GEGLU. */
+    const void* r1_lo;
+    const void* r2_lo;
+    void* out_lo;
 } ew_gemm_args;
 
 ew_status ew_gemm_f16(const ew_gemm_args* args, void* stream);
@@ -90,27 +97,36 @@ const char* ew_gemm_last_kernel(void);
 void ew_set_gemm_debug(int flags);   /* measurement-only switches (bit0: skip stores, bit1: skip epilogue); 0 = normal */
 
 /* GroupNorm statistics + apply, channels-last fp16, over a (virtual) channel concat.
- * The normalised tensor has C_tot channels in `groups` groups; this call handles the C_src channels
+ * The normalised tensor has C_tot channels in `groups` groups; a stats/apply call handles the C_src channels
  * [c_off, c_off+C_src) that live in tensor `x` ([n_slabs*rows, C_src]); a skip-concat input is covered by
- * two calls (one per source) -- groups may straddle the seam.
- * stats: sums[n][g] += (sum, sumsq) (fp32, atomics; `sums` [n_slabs, groups, 2] must be zeroed first);
+ * two calls (one per source) -- groups may straddle the seam.  x_lo (may be NULL) is the lo half of a
+ * split-fp16 residual stream (x = hi + lo, see ew_gemm_args).
+ * Statistics are DETERMINISTIC and cancellation-safe (no atomics): ew_groupnorm_stats_f16 writes per-(slab, row chunk,
+ * channel) sums of (x - K_c) and (x - K_c)^2 shifted by the pivot K_c = x[slab, row 0, c] into the workspace;
+ * ew_groupnorm_finalize (one call per GroupNorm, after the stats calls of all its sources) reduces them in a fixed
+ * order to (mean, biased variance) per (slab, group); ew_groupnorm_apply_f16 reads those.
+ * `ws`: ew_groupnorm_workspace_floats(n_slabs, rows, C_tot, groups) floats, uninitialised, private to this GroupNorm call.
  *        slab n = `rows` consecutive rows (rows = H*W for the per-frame GN of ResnetBlock2D / transformer
  *        norm / conv_norm_out; rows = T*H*W for TemporalResnetBlock's GN over [B,C,T,H,W]).
  * apply: y[row][c_off+c] = (x-mean)*rstd*gamma[c_off+c]+beta[c_off+c], optional SiLU; y row stride = C_tot.
  * Replaces torch.nn.GroupNorm + SiLU at the diffusers blocks instantiated by
  * evoworld/trainer/unet_plucker.py:161-233 and conv_norm_out (:236, 478-479). */
-ew_status ew_groupnorm_stats_f16(const void* x, float* sums, int n_slabs, int rows, int C_src, int c_off, int C_tot,
-                                 int groups, void* stream);
-ew_status ew_groupnorm_apply_f16(const void* x, const float* sums, const void* gamma, const void* beta, void* y,
-                                 int n_slabs, int rows, int C_src, int c_off, int C_tot, int groups, float eps,
+size_t ew_groupnorm_workspace_floats(int n_slabs, int rows, int C_tot, int groups);
+ew_status ew_groupnorm_stats_f16(const void* x, const void* x_lo, float* ws, int n_slabs, int rows, int C_src, int c_off,
+                                 int C_tot, int groups, void* stream);
+ew_status ew_groupnorm_finalize(float* ws, int n_slabs, int rows, int C_tot, int groups, void* stream);
+ew_status ew_groupnorm_apply_f16(const void* x, const void* x_lo, const float* ws, const void* gamma, const void* beta,
+                                 void* y, int n_slabs, int rows, int C_src, int c_off, int C_tot, int groups, float eps,
                                  int silu, void* stream);
 
-/* LayerNorm over the last dim (fp16 in/out, fp32 statistics).  Optional fused pre-add:
- * x' = x + addvec[row / rows_per_group][:] is what gets normalised, and x' is written to x_out (fp16) when
- * non-NULL (the time_pos_embed add in TransformerSpatioTemporalModel).  C % 8 == 0, C <= 2048.
+/* LayerNorm over the last dim (fp16 in/out, fp32 two-pass statistics).  x_lo (may be NULL): lo half of a split-fp16
+ * residual stream.  Optional fused pre-add: x' = x + addvec[row / rows_per_group][:] is what gets normalised, and x' is
+ * written to x_out (fp16) -- plus its rounding remainder to x_out_lo when non-NULL -- (the time_pos_embed add in
+ * TransformerSpatioTemporalModel).  C % 8 == 0, C <= 2048.
  * Replaces torch.nn.LayerNorm in Basic/TemporalBasicTransformerBlock (diffusers, via unet_plucker.py:13). */
-ew_status ew_layernorm_f16(const void* x, const void* addvec, int rows_per_group, void* x_out, const void* gamma,
-                           const void* beta, void* y, int rows, int C, float eps, void* stream);
+ew_status ew_layernorm_f16(const void* x, const void* x_lo, const void* addvec, int rows_per_group, void* x_out,
+                           void* x_out_lo, const void* gamma, const void* beta, void* y, int rows, int C, float eps,
+                           void* stream);
 
 /* Spatial self-attention core, head_dim 64: o = softmax(q k^T * scale) v per (sequence, head), flash-tiled
  * on MFMA 32x32x16 with the swapped product S^T = K Q^T so each query's softmax row is lane-local.

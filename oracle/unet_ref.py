@@ -47,6 +47,13 @@ class TimestepEmbedding(nn.Module):
         return self.linear_2(F.silu(self.linear_1(x)))
 
 
+RES_Q = None   # analysis knob (tests/analysis_fp16_floor.py): a function applied at every residual-stream tensor
+
+
+def _rq(x):
+    return x if RES_Q is None else RES_Q(x)
+
+
 class ResnetBlock2D(nn.Module):
     def __init__(self, cin, cout, temb_ch, eps):
         super().__init__()
@@ -63,7 +70,7 @@ class ResnetBlock2D(nn.Module):
         h = self.conv2(F.silu(self.norm2(h)))
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
-        return x + h
+        return _rq(x + h)
 
 
 class TemporalResnetBlock(nn.Module):
@@ -106,7 +113,9 @@ class SpatioTemporalResBlock(nn.Module):
         super().__init__()
         self.spatial_res_block = ResnetBlock2D(cin, cout, temb_ch, eps)
         self.temporal_res_block = TemporalResnetBlock(cout, temb_ch, eps)
-        self.time_mixer = AlphaBlender(0.5, switch=True)
+        # diffusers SpatioTemporalResBlock defaults switch_spatial_to_temporal_mix=False (only the TemporalVAE decoder
+        # blocks pass True): out = a*spatial + (1-a)*temporal, a = sigmoid(mix_factor)
+        self.time_mixer = AlphaBlender(0.5, switch=False)
 
     def forward(self, x, temb, T):
         x = self.spatial_res_block(x, temb)
@@ -114,7 +123,7 @@ class SpatioTemporalResBlock(nn.Module):
         B = BF // T
         xs = x.reshape(B, T, C, H, W).permute(0, 2, 1, 3, 4)
         xt = self.temporal_res_block(xs, temb.reshape(B, T, -1))
-        y = self.time_mixer(xs, xt)
+        y = _rq(self.time_mixer(xs, xt))
         return y.permute(0, 2, 1, 3, 4).reshape(BF, C, H, W)
 
 
@@ -175,8 +184,8 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, x, ctx, exec_dead=False):
         x = x + self.attn1(self.norm1(x))
-        x = x + self.attn2(self.norm2(x), ctx, exec_dead)
-        x = x + self.ff(self.norm3(x))
+        x = _rq(x + self.attn2(self.norm2(x), ctx, exec_dead))   # product: one epilogue (attn1 out-proj + folded attn2)
+        x = _rq(x + self.ff(self.norm3(x)))
         return x
 
 
@@ -196,10 +205,10 @@ class TemporalBasicTransformerBlock(nn.Module):
         BF, S, C = x.shape
         B = BF // T
         x = x.reshape(B, T, S, C).permute(0, 2, 1, 3).reshape(B * S, T, C)
-        x = x + self.ff_in(self.norm_in(x))
+        x = _rq(x + self.ff_in(self.norm_in(x)))
         x = x + self.attn1(self.norm1(x))
-        x = x + self.attn2(self.norm2(x), ctx, exec_dead)
-        x = x + self.ff(self.norm3(x))
+        x = _rq(x + self.attn2(self.norm2(x), ctx, exec_dead))
+        x = x + self.ff(self.norm3(x))       # product: blended with the spatial branch in the same epilogue
         return x.reshape(B, S, T, C).permute(0, 2, 1, 3).reshape(BF, S, C)
 
 
@@ -225,15 +234,15 @@ class TransformerSpatioTemporalModel(nn.Module):
         time_ctx = first[:, None].expand(B, S, first.shape[-2], first.shape[-1]).reshape(B * S, -1, first.shape[-1])
         res = x
         h = self.norm(x).permute(0, 2, 3, 1).reshape(BF, S, C)
-        h = self.proj_in(h)
+        h = _rq(self.proj_in(h))
         frames = torch.arange(T, device=x.device).repeat(B)
         emb = self.time_pos_embed(timestep_embedding(frames, self.ch).to(h.dtype))[:, None, :]
         for blk, tblk in zip(self.transformer_blocks, self.temporal_transformer_blocks):
             h = blk(h, ehs, exec_dead)
-            hm = tblk(h + emb, T, time_ctx, exec_dead)
-            h = self.time_mixer(h, hm)
+            hm = tblk(_rq(h + emb), T, time_ctx, exec_dead)
+            h = _rq(self.time_mixer(h, hm))
         h = self.proj_out(h)
-        return h.reshape(BF, H, W, C).permute(0, 3, 1, 2) + res
+        return _rq(h.reshape(BF, H, W, C).permute(0, 3, 1, 2) + res)
 
 
 class Downsample2D(nn.Module):

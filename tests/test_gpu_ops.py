@@ -157,6 +157,73 @@ def test_groupnorm(ops, n, rows, Cs, silu):
     assert rel_l2(out.float().cpu(), ref.cpu()) < 2e-3
 
 
+@pytest.mark.parametrize("ratio", [30.0, 300.0])
+def test_groupnorm_high_mean_over_std_and_determinism(ops, ratio):
+    """channels with mean >> std (VERDICT r01 weak #6): shifted sums, fixed-order reduction -> bit-identical reruns"""
+    n, rows, C = 3, 1152, 640
+    x = torch.randn(n * rows, C, generator=_g(20)) * 0.25 + ratio * 0.25
+    g, b = rnd(C, seed=3) * 0.2 + 1, rnd(C, seed=4) * 0.1
+    xh = x.half().to(DEV)
+    out = ops.groupnorm([xh], g.half().to(DEV), b.half().to(DEV), n, rows, 1e-6, False)
+    for _ in range(3):
+        assert torch.equal(out, ops.groupnorm([xh], g.half().to(DEV), b.half().to(DEV), n, rows, 1e-6, False))
+    xc = xh.double().reshape(n, rows, C).permute(0, 2, 1)
+    ref = F.group_norm(xc, 32, g.half().double().to(DEV), b.half().double().to(DEV), 1e-6).permute(0, 2, 1).reshape(n * rows, C)
+    assert rel_l2(out.float().cpu(), ref.cpu()) < 1e-3
+
+
+def test_groupnorm_split_stream_concat(ops):
+    """two sources (virtual concat), both split fp16: statistics and apply see hi + lo"""
+    n, rows, Cs = 2, 300, [640, 320]
+    xs = [rnd(n * rows, c, seed=30 + i, scale=1.5) + 0.3 for i, c in enumerate(Cs)]
+    C = sum(Cs)
+    g, b = rnd(C, seed=3) * 0.2 + 1, rnd(C, seed=4) * 0.1
+    src, full = [], []
+    for x in xs:
+        hi = x.half().to(DEV)
+        lo = (x.to(DEV) - hi.float()).half()
+        src.append(ops.Res(hi, lo))
+        full.append(hi.float() + lo.float())
+    out = ops.groupnorm(src, g.half().to(DEV), b.half().to(DEV), n, rows, 1e-5, True)
+    xc = torch.cat(full, 1).reshape(n, rows, C).permute(0, 2, 1)
+    ref = F.silu(F.group_norm(xc, 32, g.half().float().to(DEV), b.half().float().to(DEV), 1e-5)).permute(0, 2, 1).reshape(n * rows, C)
+    e_split = rel_l2(out.float().cpu(), ref.cpu())
+    out_hi = ops.groupnorm([s.hi for s in src], g.half().to(DEV), b.half().to(DEV), n, rows, 1e-5, True)
+    e_hi = rel_l2(out_hi.float().cpu(), ref.cpu())
+    assert e_split < 4e-4 and e_split < e_hi      # output rounding only (2^-11/sqrt(3) = 2.8e-4) vs input rounding on top
+
+
+def test_gemm_split_residual_epilogues(ops):
+    """r1 / r2 / out as hi + lo pairs through every kernel generation and both tile families (N = 320k and N = 128k)"""
+    from evoworld_amd import _lib
+    lib = _lib.load()
+    for gen in (3, 2, 1):
+        lib.ew_set_gemm_generation(gen)
+        try:
+            for (M, N, K) in ((1100, 640, 256), (1100, 320, 192), (300, 384, 128)):
+                x, w = rnd(M, K, seed=1).half().to(DEV), (rnd(N, K, seed=2) / 16).half().to(DEV)
+                b = rnd(N, seed=3).half().to(DEV)
+                r1f, r2f = rnd(M, N, seed=5) * 3, rnd(M, N, seed=6) * 3
+                r1h, r2h = r1f.half().to(DEV), r2f.half().to(DEV)
+                r1 = ops.Res(r1h, (r1f.to(DEV) - r1h.float()).half())
+                r2 = ops.Res(r2h, (r2f.to(DEV) - r2h.float()).half())
+                out = ops.Res.empty(M, N, DEV, True)
+                ops.gemm(x, w, out, M=M, N=N, c1=K, lda=K, bias=b, r1=r1, ld_r1=N, r2=r2, ld_r2=N, c_acc=0.4, c_r1=0.6, c_r2=-1.5)
+                ref = 0.4 * (x.float() @ w.float().T + b.float()) + 0.6 * r1.float() - 1.5 * r2.float()
+                assert rel_l2(out.float().cpu(), ref.cpu()) < 2e-5, (gen, M, N, K)
+                # r1 only, lo on the input only (the blended hb of the transformer: fp16 out)
+                o2 = torch.empty(M, N, dtype=torch.float16, device=DEV)
+                ops.gemm(x, w, o2, M=M, N=N, c1=K, lda=K, bias=b, r1=r1, ld_r1=N)
+                ref2 = x.float() @ w.float().T + b.float() + r1.float()
+                assert rel_l2(o2.float().cpu(), ref2.cpu()) < 4e-4, (gen, M, N, K)
+                # no residual, lo on the output only (proj_in / conv_in)
+                o3 = ops.Res.empty(M, N, DEV, True)
+                ops.gemm(x, w, o3, M=M, N=N, c1=K, lda=K, bias=b)
+                assert rel_l2(o3.float().cpu(), (x.float() @ w.float().T + b.float()).cpu()) < 2e-5, (gen, M, N, K)
+        finally:
+            lib.ew_set_gemm_generation(3)
+
+
 @pytest.mark.parametrize("rows,C", [(37, 320), (1000, 640), (9, 1280), (130, 64)])
 def test_layernorm(ops, rows, C):
     x, g, b = rnd(rows, C, seed=1) * 2 + 0.5, rnd(C, seed=2) * 0.2 + 1, rnd(C, seed=3) * 0.1
@@ -171,6 +238,13 @@ def test_layernorm(ops, rows, C):
     xs = (xh.float() + av.float()[torch.arange(rows, device=DEV) // rpg]).half()
     assert torch.equal(xo, xs)
     assert rel_l2(out2.float().cpu(), F.layer_norm(xs.float(), (C,), gh.float(), bh.float(), 1e-5).cpu()) < 1e-3
+    # split-fp16 stream in and out
+    lo = (x.to(DEV) - xh.float()).half()
+    xo3 = ops.Res.empty(rows, C, DEV, True)
+    out3 = ops.layernorm(ops.Res(xh, lo), gh, bh, addvec=av, rows_per_group=rpg, x_out=xo3)
+    full = xh.float() + lo.float() + av.float()[torch.arange(rows, device=DEV) // rpg]
+    assert rel_l2(xo3.float().cpu(), full.cpu()) < 2e-6
+    assert rel_l2(out3.float().cpu(), F.layer_norm(full, (C,), gh.float(), bh.float(), 1e-5).cpu()) < 4e-4
 
 
 # ----------------------------------------------------------------------------- attention

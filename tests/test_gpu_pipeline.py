@@ -7,6 +7,13 @@ from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
 
+# Stated tolerances = 1.5 x the values measured on MI355X with the split-fp16 residual stream, so a 2x
+# regression fails: 3-step clips measure 1.24e-3 / 1.40e-3 (mask_mem), the 25-step clip 4.1e-4, the 2-step clip on the
+# smooth stand-in VAE latents 2.2e-3 (two steps = sigma 700 -> 0.002 -> 0: the output is one raw model prediction).
+TOL_CLIP3 = 2.1e-3
+TOL_CLIP25 = 6.2e-4
+TOL_CLIP2_STANDIN = 3.4e-3
+
 
 class _FakeVAE:
     """Deterministic stand-in with the VAE duck type (encode(x).latent_dist.mode(), decode(z,num_frames).sample)."""
@@ -35,7 +42,7 @@ class _FakeCLIP:
         return type("O", (), {"image_embeds": v})
 
 
-def _oracle_loop(ref, lat0, il, ehs, pl, T, steps, mask_mem=False):
+def _oracle_loop(ref, lat0, il, ehs, pl, T, steps, mask_mem=False, trace=None):
     from evoworld_amd.scheduler import EulerDiscreteScheduler
     from oracle.reproject_ref import euler_cfg_step_ref
     s = EulerDiscreteScheduler()
@@ -53,6 +60,8 @@ def _oracle_loop(ref, lat0, il, ehs, pl, T, steps, mask_mem=False):
         x = torch.cat([torch.cat([lat, lat]) / (sig ** 2 + 1) ** 0.5, cond], dim=2)
         eps = ref(x, s.timesteps[i], e2, ids)
         lat = euler_cfg_step_ref(eps[0:1], eps[1:2], lat, guid, sig, sign)
+        if trace is not None:
+            trace.append(lat.clone())
     return lat
 
 
@@ -82,7 +91,34 @@ def test_denoise_loop_vs_oracle(models, mask_mem):
     want = _oracle_loop(ref, lat0, il, ehs, pl, T, steps, mask_mem)
     e = rel_l2(out.cpu(), want)
     print(f"denoise loop ({steps} steps, mask_mem={mask_mem}) rel-L2 {e:.3e}")
-    assert e < 5e-3
+    assert e < TOL_CLIP3
+
+
+def test_denoise_25_steps_error_curve(models):
+    """The full 25-step Euler schedule (evoworld/pipeline/pipeline_evoworld.py:689-725) on the tiny config: per-step rel-L2
+    of the latents against the fp32 oracle loop.  sigma falls from 700 to 0, so early steps are dominated by the (exactly
+    shared) noise and the distance grows as the model output takes over."""
+    cfg, ref, unet, Pipe = models
+    T, h, w, steps = 4, 16, 32, 25
+    g = torch.Generator().manual_seed(7)
+    lat0, il = torch.randn(1, T, 4, h, w, generator=g), torch.randn(1, T + 1, 4, h, w, generator=g)
+    ehs, pl = torch.randn(1, 1, cfg["cross_attention_dim"], generator=g), torch.randn(1, T, 6, h, w, generator=g)
+    pipe = Pipe(unet=unet)
+    got = []
+    out = pipe(torch.zeros(1, 3, h * 8, w * 8), height=h * 8, width=w * 8, num_frames=T, num_inference_steps=steps, latents=lat0,
+               output_type="latent", plucker_embedding=pl, image_latents=il, image_embeddings=ehs,
+               callback_on_step_end=lambda p, i, t, kw: got.append(kw["latents"].detach().cpu().clone()) or {}).frames
+    want = []
+    final = _oracle_loop(ref, lat0, il, ehs, pl, T, steps, trace=want)
+    curve = [rel_l2(a, b) for a, b in zip(got, want)]
+    print("25-step error curve:", " ".join(f"{e:.2e}" for e in curve))
+    e = rel_l2(out.cpu(), final)
+    print(f"denoise loop (25 steps) final rel-L2 {e:.3e}")
+    assert len(curve) == steps and e < TOL_CLIP25
+    # run-to-run reproducibility: deterministic GroupNorm statistics -> bit-identical clips
+    out2 = pipe(torch.zeros(1, 3, h * 8, w * 8), height=h * 8, width=w * 8, num_frames=T, num_inference_steps=steps, latents=lat0,
+                output_type="latent", plucker_embedding=pl, image_latents=il, image_embeddings=ehs).frames
+    assert rel_l2(out2.cpu(), out.cpu()) <= 1e-4
 
 
 def test_full_call_surface_with_component_duck_types(models):
@@ -112,7 +148,9 @@ def test_full_call_surface_with_component_duck_types(models):
     want = _oracle_loop(ref, lat0, il, ehs, pl, T, steps)
     got = pipe(image.cuda(), height=H, width=W, num_frames=T, num_inference_steps=steps, generator=torch.Generator().manual_seed(123),
                plucker_embedding=pl, memorized_pixel_values=memory.cuda(), output_type="latent").frames
-    assert rel_l2(got.cpu(), want) < 5e-3
+    e = rel_l2(got.cpu(), want)
+    print(f"2-step clip through the component duck types rel-L2 {e:.3e}")
+    assert e < TOL_CLIP2_STANDIN
 
 
 def test_input_validation_matches_reference(models):

@@ -1,7 +1,10 @@
 """-m gpu: the HIP U-Net (through the C ABI) against the fp32 CPU oracle on the same seeded weights/inputs.
-Tolerance (stated): the product computes in fp16 storage / fp32 accumulation; against the fp32 oracle run on the
-same fp16-representable checkpoint the end-to-end rel-L2 of one U-Net forward must be <= 5e-3 (tiny config),
-each tapped block output <= 5e-3.  BASELINE.json's 1e-3 target is tracked in DESIGN.md (measured value printed)."""
+Tolerance (stated): fp16 MFMA operands, fp32 accumulation, split-fp16 (hi + lo) residual stream.  Against the fp32 oracle
+on the same fp16-representable checkpoint one U-Net forward measures 8.9e-4 rel-L2 end to end (BASELINE.json: 1e-3) and
+<= 1.24e-3 at every tapped block output; the assertions are 1.5 x the measured values so that a 2x regression fails
+(the plain-fp16 stream, EW_RESIDUAL=fp16, measures 1.33e-3 and fails them)."""
+TOL_FORWARD = 1.3e-3
+TOL_TAP = 1.9e-3
 import pytest
 import torch
 
@@ -45,7 +48,7 @@ def test_unet_tiny_vs_oracle():
     e = rel_l2(got.cpu(), want)
     print(f"unet tiny forward rel-L2 {e:.3e}")
     assert torch.isfinite(got).all()
-    assert worst < 5e-3 and e < 5e-3
+    assert worst < TOL_TAP and e < TOL_FORWARD
 
 
 def test_unet_tiny_T25_ragged_spatial():
@@ -60,7 +63,19 @@ def test_unet_tiny_T25_ragged_spatial():
     got = m(x.cuda(), t, ehs.cuda(), ids.cuda(), return_dict=False)[0]
     e = rel_l2(got.cpu(), want)
     print(f"unet tiny T=25 forward rel-L2 {e:.3e}")
-    assert e < 5e-3
+    assert e < TOL_FORWARD
+
+
+def test_unet_forward_bit_reproducible():
+    """deterministic GroupNorm statistics (no atomics): two runs of the same forward are bit-identical"""
+    from oracle.unet_ref import tiny_config
+    cfg = tiny_config()
+    B, T, h, w = 2, 4, 16, 32
+    m, _, x, ehs, ids = _setup(cfg, B, T, h, w)
+    t = torch.tensor(0.5)
+    a = m(x.cuda(), t, ehs.cuda(), ids.cuda(), return_dict=False)[0]
+    b = m(x.cuda(), t, ehs.cuda(), ids.cuda(), return_dict=False)[0]
+    assert torch.equal(a, b)
 
 
 def test_unet_dead_cross_attention_identity():
