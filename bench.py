@@ -82,9 +82,10 @@ def kernel_breakdown(unet, pipe, latents, image_latents, ehs, plucker, T, h, w, 
     from evoworld_amd import _lib
     lib = _lib.load()
     rec = []
-    names = ("ew_gemm_f16", "ew_groupnorm_stats_f16", "ew_groupnorm_apply_f16", "ew_layernorm_f16", "ew_attn_spatial_f16",
-             "ew_attn_temporal_f16")
-    kname = {"ew_groupnorm_stats_f16": "gn_stats_kernel", "ew_groupnorm_apply_f16": "gn_apply_kernel",
+    names = ("ew_gemm_f16", "ew_groupnorm_stats_f16", "ew_groupnorm_finalize", "ew_groupnorm_apply_f16", "ew_layernorm_f16",
+             "ew_attn_spatial_f16", "ew_attn_temporal_f16")
+    kname = {"ew_groupnorm_stats_f16": "gn_stats_kernel", "ew_groupnorm_finalize": "gn_finalize_kernel",
+             "ew_groupnorm_apply_f16": "gn_apply_kernel",
              "ew_layernorm_f16": "ln_kernel", "ew_attn_spatial_f16": "attn_spatial_kernel", "ew_attn_temporal_f16": "attn_temporal_kernel"}
     orig = {n: getattr(lib, n) for n in names}
 
@@ -125,7 +126,13 @@ def kernel_breakdown(unet, pipe, latents, image_latents, ehs, plucker, T, h, w, 
         t[0] += 1
         t[1] += s.elapsed_time(e)
         t[2] += fl
-    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    if os.environ.get("EW_BENCH_FULL_BREAKDOWN"):
+        tot = sum(v[1] for _, v in rows)
+        for key, (n, ms, fl) in rows:
+            print(f"  {key:48s} n={n:4d} total {ms:7.2f} ms  avg {ms / n * 1e3:8.1f} us" + (f"  {fl / ms / 1e9:7.1f} TF/s" if fl else ""), file=sys.stderr)
+        print(f"  sum of launches {tot:.2f} ms", file=sys.stderr)
+    rows = rows[:top]
     out = []
     for key, (n, ms, fl) in rows:
         d = {"kernel": key, "launches_per_forward": n, "avg_us": round(ms / n * 1e3, 1), "total_ms": round(ms, 2)}

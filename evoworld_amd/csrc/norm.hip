@@ -122,41 +122,59 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, const f16* __restrict
     }
 }
 
-// one wave per (slab, group): stats[slab][g] = (mean, biased variance)
+// one 256-thread block per (slab, group): stats[slab][g] = (mean, biased variance).  Thread (kc, c) sums the chunks
+// kc, kc+KP, ... of channel c in order; the KP chunk-lanes of a channel are combined in order through LDS; the group's
+// channels go through a fixed shuffle tree.  (One wave per group looping over all chunks took 29 us per call.)
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ pivot,
                                                           float* __restrict__ stats, int n_slabs, int rows, int C_tot,
                                                           int groups, int chunks) {
-    const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wid >= n_slabs * groups) return;
-    const int slab = wid / groups, g = wid - slab * groups;
+    __shared__ float red[2][256];
+    __shared__ float chan[2][512];             // per-channel mean, M2 (gs <= 512)
+    __shared__ float wsum[4];
+    const int tid = threadIdx.x;
+    const int slab = blockIdx.x / groups, g = blockIdx.x - slab * groups;
     const int gs = C_tot / groups;
     const float n = (float)rows;
-    // per-channel mean and M2 (lane-strided channels of the group), chunks summed in order
-    float msum = 0.f, m2sum = 0.f;             // over this lane's channels: sum of mean_c, sum of M2_c
-    float mloc[8];                             // this lane's channel means (gs <= 512)
-    int nloc = 0;
-    for (int c = lane; c < gs; c += 64) {
-        const int ch = g * gs + c;
+    const int cw = gs < 256 ? gs : 256;        // channels handled per pass
+    const int KP = 256 / cw;                   // chunk-lanes per channel
+    for (int c0 = 0; c0 < gs; c0 += cw) {
+        const int c = c0 + tid % cw, kc = tid / cw;
         float ss = 0.f, qq = 0.f;
-        const float* p = part + (((size_t)slab * chunks) * C_tot + ch) * 2;
-        for (int k = 0; k < chunks; ++k) {
-            const f32x2 v = *(const f32x2*)(p + (size_t)k * C_tot * 2);
-            ss += v[0];
-            qq += v[1];
+        if (kc < KP && c < gs) {
+            const float* p = part + (((size_t)slab * chunks) * C_tot + g * gs + c) * 2;
+            for (int k = kc; k < chunks; k += KP) {
+                const f32x2 v = *(const f32x2*)(p + (size_t)k * C_tot * 2);
+                ss += v[0];
+                qq += v[1];
+            }
         }
-        const float d = ss / n;
-        const float mc = pivot[(size_t)slab * C_tot + ch] + d;
-        m2sum += fmaxf(qq - ss * d, 0.f);
-        msum += mc;
-        if (nloc < 8) mloc[nloc] = mc;
-        ++nloc;
+        red[0][tid] = ss;
+        red[1][tid] = qq;
+        __syncthreads();
+        if (tid < cw && c0 + tid < gs) {
+            float s2 = 0.f, q2 = 0.f;
+            for (int k = 0; k < KP; ++k) { s2 += red[0][k * cw + tid]; q2 += red[1][k * cw + tid]; }
+            const float d = s2 / n;
+            chan[0][c0 + tid] = pivot[(size_t)slab * C_tot + g * gs + c0 + tid] + d;     // channel mean
+            chan[1][c0 + tid] = fmaxf(q2 - s2 * d, 0.f);                                  // channel M2
+        }
+        __syncthreads();
     }
-    const float mean = wave_sum(msum) / (float)gs;
+    // across the group's channels: mean = avg(mean_c); M2 = sum(M2_c) + n * sum((mean_c - mean)^2)
+    float ms = 0.f, m2 = 0.f;
+    for (int c = tid; c < gs; c += 256) { ms += chan[0][c]; m2 += chan[1][c]; }
+    ms = wave_sum(ms);
+    m2 = wave_sum(m2);
+    if ((tid & 63) == 0) wsum[tid >> 6] = ms;
+    __syncthreads();
+    const float mean = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)gs;
+    __syncthreads();
     float dev = 0.f;
-    for (int k = 0; k < nloc && k < 8; ++k) { const float d = mloc[k] - mean; dev += d * d; }
-    const float var = (wave_sum(m2sum) + n * wave_sum(dev)) / (n * (float)gs);
-    if (lane == 0) *(f32x2*)(stats + (size_t)wid * 2) = (f32x2){mean, var};
+    for (int c = tid; c < gs; c += 256) { const float d = chan[0][c] - mean; dev += d * d; }
+    dev = wave_sum(dev);
+    if ((tid & 63) == 0) { wsum[tid >> 6] = m2 + n * dev; }
+    __syncthreads();
+    if (tid == 0) *(f32x2*)(stats + (size_t)blockIdx.x * 2) = (f32x2){mean, (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (n * (float)gs)};
 }
 
 // GroupNorm apply (+SiLU).  Same thread layout as the statistics kernel: grid = (row chunks, n_slabs), block = PL * VPP
@@ -296,7 +314,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, cons
                         const float sum = v[r][k][e] + (float)add[r][k][e];
                         xo[e] = (f16)sum;
                         xl[e] = (f16)(sum - (float)xo[e]);
-                        v[r][k][e] = x_out_lo ? (float)xo[e] + (float)xl[e] : (float)xo[e];
+                        v[r][k][e] = !x_out ? sum : (x_out_lo ? (float)xo[e] + (float)xl[e] : (float)xo[e]);   // not materialised: exact
                     }
                     if (x_out && live) *(f16x8*)(x_out + (size_t)row * C + vi * 8) = xo;
                     if (x_out_lo && live) *(f16x8*)(x_out_lo + (size_t)row * C + vi * 8) = xl;
@@ -377,7 +395,7 @@ extern "C" ew_status ew_groupnorm_finalize(float* ws, int n_slabs, int rows, int
     EW_REQUIRE(n_slabs > 0 && rows > 0 && groups > 0 && C_tot % groups == 0 && C_tot / groups <= 512,
                "ew_groupnorm_finalize: bad shape");
     const GnWs w = gn_ws(ws, n_slabs, rows, C_tot);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(ew_cdiv((long long)n_slabs * groups, 4)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_slabs * groups), dim3(256), 0, (hipStream_t)stream,
                        w.part, w.pivot, w.stats, n_slabs, rows, C_tot, groups, w.chunks);
     return ew_check_launch("ew_groupnorm_finalize");
 }

@@ -467,10 +467,13 @@ class UNetSpatioTemporalConditionModel:
         h = ops.linear(ffh, d["s_f2w"], d["s_f2b"], out=self._res(rows, C, dev), r1=h, ld_r1=C)
         del ffh
         # --- TemporalBasicTransformerBlock on frame-major tokens (regroup = addressing) ---
-        hm = self._res(rows, C, dev)
-        nin = ops.layernorm(h, d["t_norm_ing"], d["t_norm_inb"], addvec=self._pos_emb(t, B, T), rows_per_group=S, x_out=hm)
+        # x_temporal stream starts as h + time_pos_embed: the sum is formed inside the LayerNorm (for norm_in) and again in
+        # the ff_in epilogue (r1 = h, row-bias = the frame's embedding) -- it is never written to HBM
+        pos = self._pos_emb(t, B, T)
+        nin = ops.layernorm(h, d["t_norm_ing"], d["t_norm_inb"], addvec=pos, rows_per_group=S)
         ffh = ops.linear(nin, d["t_fi1w"], d["t_fi1b"], act=ACT_GEGLU)
-        hm = ops.linear(ffh, d["t_fi2w"], d["t_fi2b"], out=self._res(rows, C, dev), r1=hm, ld_r1=C)
+        hm = ops.linear(ffh, d["t_fi2w"], d["t_fi2b"], out=self._res(rows, C, dev), r1=h, ld_r1=C, rowbias=pos,
+                        rows_per_group=S, ld_rowbias=C)
         del ffh
         n1 = ops.layernorm(hm, d["t_norm1g"], d["t_norm1b"])
         qkv = ops.linear(n1, d["t_qkv"])
