@@ -20,7 +20,7 @@ SYMBOLS = [
     "ew_layernorm_f16", "ew_attn_spatial_f16", "ew_attn_temporal_f16", "ew_nchw_f32_to_nhwc_f16",
     "ew_nhwc_f16_to_nchw_f32", "ew_euler_cfg_step", "ew_plucker_embed", "ew_cube2equi_gather",
     "ew_depth_unproject", "ew_splat_cubemap", "ew_splat_resolve", "ew_equi2pers", "ew_resize_aa_u8",
-    "ew_u8_hwc_to_f32_chw",
+    "ew_u8_hwc_to_f32_chw", "ew_f32_chw_to_u8_hwc",
 ]
 
 
@@ -83,6 +83,7 @@ def load():
         "ew_equi2pers": [P, P, P, I, I, I, I, I, F, P],
         "ew_resize_aa_u8": [P, P, P, P, P, I, P, P, I, I, I, I, I, I, P],
         "ew_u8_hwc_to_f32_chw": [P, P, I, I, I, P],
+        "ew_f32_chw_to_u8_hwc": [P, P, I, I, I, P],
     }
     lib.ew_groupnorm_workspace_floats.argtypes = [c_int, c_int, c_int, c_int]
     lib.ew_groupnorm_workspace_floats.restype = c_size_t

@@ -198,7 +198,29 @@ __global__ void u8_hwc_to_f32_chw_kernel(const uint8_t* __restrict__ src, float*
     }
 }
 
+// fp32 CHW in [-1,1] -> u8 HWC: round_half_even(clamp(x/2 + 0.5, 0, 1) * 255) -- what the pipeline's PIL output holds
+// (diffusers VideoProcessor: (x/2+0.5).clamp(0,1) -> (.*255).round().astype(uint8); pipeline_evoworld.py:727-732)
+__global__ void f32_chw_to_u8_hwc_kernel(const float* __restrict__ src, uint8_t* __restrict__ dst, long long n_img, int HW) {
+    const long long total = n_img * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long img = i / HW;
+        const int p = (int)(i - img * HW);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float x = src[(img * 3 + c) * HW + p] / 2.0f + 0.5f;
+            dst[i * 3 + c] = (uint8_t)rintf(fminf(fmaxf(x, 0.f), 1.f) * 255.0f);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" ew_status ew_f32_chw_to_u8_hwc(const float* src, uint8_t* dst, int V, int H, int W, void* stream) {
+    EW_REQUIRE(src && dst && V > 0 && H > 0 && W > 0, "ew_f32_chw_to_u8_hwc: bad args");
+    hipLaunchKernelGGL(f32_chw_to_u8_hwc_kernel, dim3(grid_for((long long)V * H * W)), dim3(256), 0, (hipStream_t)stream, src,
+                       dst, (long long)V, H * W);
+    return ew_check_launch("ew_f32_chw_to_u8_hwc");
+}
 
 extern "C" ew_status ew_plucker_embed(const float* rays, const float* c2w, float* out, int N, int H, int W, void* stream) {
     EW_REQUIRE(rays && c2w && out && N > 0 && H > 0 && W > 0, "ew_plucker_embed: bad args");

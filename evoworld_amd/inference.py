@@ -56,20 +56,35 @@ def process_batch(batch, args, pipeline, rays, weight_dtype=torch.float32, outpu
 
 # ------------------------------------------------------------------ C2: windowed navigation
 class Navigator:
-    def __init__(self, pipe, height=576, width=1024, num_frames=25, fps=7):
+    def __init__(self, pipe, height=576, width=1024, num_frames=25, fps=7, step_size=0.4, position_scale=0.1):
         self.pipe, self.model_height, self.model_width, self.num_frames, self.fps = pipe, height, width, num_frames, fps
+        self.step_size, self.position_scale = step_size, position_scale            # navigator_evoworld.py:49-52
         self.rays = torch.tensor(equirectangular_to_ray(height // 8, width // 8)).float().cuda()
         self.memorized_images = None
         self.generations = []
 
     split_curve_into_segments = staticmethod(RP.split_curve_into_segments)
 
-    @staticmethod
-    def extend_segment(segment, n):
-        """Pad a short window by repeating its last pose (navigator_evoworld.py:146-154)."""
-        seg = list(segment)
-        while len(seg) < n:
-            seg.append(seg[-1].clone() if isinstance(seg[-1], torch.Tensor) else seg[-1])
+    def extend_segment(self, segment, n):
+        """Extrapolate a short window to n poses (navigator_evoworld.py:132-172): a 1-pose window steps forward by
+        step_size*position_scale along its yaw; a longer one continues with the last xyz increment, rotation held (the
+        reference asserts the last two rotations agree)."""
+        if len(segment) == 0:
+            return segment
+        seg = segment if isinstance(segment, torch.Tensor) else torch.stack(list(segment), dim=0)
+        if len(seg) == 1:
+            roty = seg[0][4]
+            dz = self.step_size * torch.cos(torch.deg2rad(roty)) * self.position_scale
+            dx = self.step_size * torch.sin(torch.deg2rad(roty)) * self.position_scale
+            step = torch.stack([dx, torch.zeros_like(dx), dz, torch.zeros_like(dx), torch.zeros_like(dx), torch.zeros_like(dx)]).to(seg)
+            return torch.cat([seg] + [seg[-1:] + step[None] * (i + 1) for i in range(n - 1)], dim=0)
+        if len(seg) < n:
+            last, prev = seg[-1], seg[-2]
+            if not torch.allclose(last[3:], prev[3:]):
+                raise AssertionError("The rotation of the last two steps are not the same.")
+            delta = last - prev
+            extra = torch.stack([last + delta * (i + 1) for i in range(n - len(seg))], dim=0)
+            return torch.cat([seg, extra], dim=0)
         return seg
 
     def move_forward(self, image, segment, num_model_frames=25, num_inference_steps=25, noise_aug_strength=0.02,
@@ -91,9 +106,20 @@ class Navigator:
                            mask_mem=not use_memory, **pipe_kw).frames
         return frames, n
 
+    @staticmethod
+    def _last_frame_tensor(frames, n):
+        """the window's last generated frame as the next window's start image (navigator :436-437: movement[-1] through
+        the ToTensor + rescale transform)"""
+        if isinstance(frames, list):                      # PIL clips [[img]*T]
+            arr = np.asarray(frames[0][n - 1].convert("RGB"))
+            return (torch.from_numpy(arr.copy()).permute(2, 0, 1).float() / 255.0 * 2 - 1).cuda()
+        raise NotImplementedError("chaining windows needs decoded frames (output_type='pil'); with output_type='latent' "
+                                  "run one window per call (infer_segment=True), as process_episode does")
+
     def navigate_curve_path(self, path, start_image, num_inference_steps=25, memorized_images=None, infer_segment=False,
                             segment_id=None, **pipe_kw):
-        """Windows [0:25],[24:49],... ; with infer_segment only window `segment_id` is generated (navigator :394-448)."""
+        """Windows [0:25],[24:49],... ; with infer_segment only window `segment_id` is generated (navigator :394-448);
+        otherwise every window starts from the previous window's last frame."""
         self.memorized_images = memorized_images.clone()
         segments = self.split_curve_into_segments(path)
         generations, current = [], 0
@@ -102,9 +128,13 @@ class Navigator:
             if segment_id is not None and current < segment_id and infer_segment:
                 current += 1
                 continue
-            frames, n = self.move_forward(image, segment, num_inference_steps=num_inference_steps,
-                                          use_memory=(segment_id != 0), **pipe_kw)
-            generations.append((frames, n))
+            if len(segment) != 0:
+                frames, n = self.move_forward(image, segment, num_inference_steps=num_inference_steps,
+                                              use_memory=(segment_id != 0), **pipe_kw)
+                generations.append((frames, n))
+                last_window = (infer_segment and current + 1 > segment_id) or segment is segments[-1]
+                if not last_window:
+                    image = self._last_frame_tensor(frames, n)
             current += 1
             if infer_segment and current > segment_id:
                 break
@@ -127,35 +157,42 @@ class UnifiedLoopConsistencyPipeline:
         self.equi2pers = RP.Equi2Pers(height=384, width=512, fov_x=90.0, mode="bilinear")      # :178-183
         self.pano_size, self.renderer = pano_size, RP.CubemapRenderer(face_res=face_res)
 
-    def convert_pano_to_pers(self, frames, camera_params, segment_id):
-        """frames float [F,3,H,W] in [-1,1] (device) -> uint8 [F,384,512,3] + target yaws in degrees (:299-334)."""
-        yaws = RP.calculate_target_yaws(camera_params, frames.shape[0], segment_id)
-        u8 = ((frames / 2 + 0.5).clamp(0, 1) * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()   # tensor_to_pil semantics
-        pers = self.equi2pers.batch(u8, [{"pitch": 0, "roll": 0, "yaw": float(y)} for y in yaws])
+    def convert_pano_to_pers(self, frames_u8, camera_params, segment_id):
+        """frames uint8 [F,H,W,3] (device; the 8-bit frames the reference holds as PIL images) -> uint8 [F,384,512,3] +
+        target yaws in degrees (:299-334).  camera_params: UNSCALED poses (camera_poses.txt)."""
+        yaws = RP.calculate_target_yaws(camera_params, frames_u8.shape[0], segment_id)
+        pers = self.equi2pers.batch(frames_u8, [{"pitch": 0, "roll": 0, "yaw": float(y)} for y in yaws])
         return pers, yaws / np.pi * 180.0
 
-    def process_episode(self, start_image, camera_params, image_latents_fn, save_dir=None, **pipe_kw):
-        """start_image float [3,H,W] in [-1,1]; camera_params [P,6] numpy (RDF, pos-scaled).  `image_latents_fn(first_frame,
-        memory [T,3,H,W]) -> dict(image_latents=[1,1+T,4,h,w], image_embeddings=[1,1,X])` stands for VAE-encode + CLIP.
-        Returns all generated frames [N,3,H,W] (25 -> 49 -> 73 ...)."""
+    def process_episode(self, start_image, camera_params, image_latents_fn, save_dir=None, pos_scale=0.1, **pipe_kw):
+        """start_image float [3,H,W] in [-1,1]; camera_params [P,6] numpy: the UNSCALED RDF poses of camera_poses.txt
+        (unified_loop_consistency.py:370-395), used as they are for the target yaws and the reprojection alignment; the
+        Navigator / Plücker path gets the copy with xyz * pos_scale that the dataset hands out as batch['cam_traj']
+        (dataset/CameraTrajDataset.py:223,348).  `image_latents_fn(first_frame, memory [T,3,H,W]) ->
+        dict(image_latents=[1,1+T,4,h,w], image_embeddings=[1,1,X])` stands for VAE-encode + CLIP.
+        Every generated frame is carried as the 8-bit image the reference's PIL frames hold (:418-419, navigator :214-226).
+        Returns all generated frames float [N,3,H,W] in [-1,1] (25 -> 49 -> 73 ...), values on the 8-bit grid."""
+        from . import ops
         dev = start_image.device
+        camera_params = np.asarray(camera_params, dtype=np.float64)
         cam_t = torch.tensor(camera_params, dtype=torch.float32, device=dev)
-        all_frames = None
+        cam_t[:, :3] *= pos_scale
+        all_u8 = None
         memory = torch.zeros(self.num_frames, 3, self.height, self.width, device=dev)       # 'empty_with_traj' memory
         for seg in range(self.num_segments):
             start_idx, end_idx, _ = RP.calculate_segment_indices(seg)
-            first = start_image if seg == 0 else all_frames[-1]
+            first = start_image if seg == 0 else ops.u8_hwc_to_f32_chw(all_u8[-1:])[0]    # pil_to_tensor(tensor_to_pil(.)) (:418-419)
             cond = image_latents_fn(first, memory)
             gens = self.nav.navigate_curve_path(cam_t, first, num_inference_steps=self.steps, memorized_images=memory[None],
                                                 infer_segment=True, segment_id=seg, output_type="latent", **cond, **pipe_kw)
             latents, _n = gens[-1]
-            frames = self.frames_from_latents(latents)
-            if all_frames is not None:
-                frames = frames[1:]                                                     # drop the duplicated first frame (:427-429)
-            all_frames = frames if all_frames is None else torch.cat([all_frames, frames], dim=0)
+            frames_u8 = ops.f32_chw_to_u8_hwc(self.frames_from_latents(latents).float().contiguous())
+            if all_u8 is not None:
+                frames_u8 = frames_u8[1:]                                               # drop the duplicated first frame (:427-429)
+            all_u8 = frames_u8 if all_u8 is None else torch.cat([all_u8, frames_u8], dim=0)
             if seg < self.num_segments - 1:
-                pers, target_yaws = self.convert_pano_to_pers(all_frames, camera_params, seg)
-                temp_cam = np.array(camera_params, dtype=np.float64).copy()
+                pers, target_yaws = self.convert_pano_to_pers(all_u8, camera_params, seg)
+                temp_cam = camera_params.copy()
                 s = max(0, end_idx - len(target_yaws))
                 temp_cam[s:end_idx, 4] = target_yaws[: end_idx - s]                        # :456-459
                 preds = self.depth_model(pers)
@@ -166,7 +203,8 @@ class UnifiedLoopConsistencyPipeline:
                                                       return_device_tensor=True, save_png=bool(save_dir))
                 mem24 = RP.memory_to_pixel_values(panos, self.height, self.width)           # [24,3,H,W]
                 memory = torch.cat([start_image[None], mem24], dim=0)                      # [episode frame 1] + 24 reprojected (:277-279)
-        return all_frames
+        self.last_frames_u8 = all_u8
+        return ops.u8_hwc_to_f32_chw(all_u8)
 
 
 class _Sized:

@@ -281,6 +281,16 @@ def u8_hwc_to_f32_chw(src):
     return dst
 
 
+def f32_chw_to_u8_hwc(src):
+    """fp32 [V,3,H,W] in [-1,1] -> uint8 [V,H,W,3] (round-half-even of clamp(x/2+0.5,0,1)*255: the pipeline's PIL frames)."""
+    lib = _lib.load()
+    _req(src, torch.float32, "src")
+    V, _, H, W = src.shape
+    dst = torch.empty(V, H, W, 3, dtype=torch.uint8, device=src.device)
+    _lib.check(lib.ew_f32_chw_to_u8_hwc(_ptr(src), _ptr(dst), V, H, W, _stream()), "ew_f32_chw_to_u8_hwc")
+    return dst
+
+
 def pack_conv_weight(w, cpad=None):
     """[O, I, *taps] (Conv2d 3x3 / Conv3d (3,1,1)) fp32 -> fp16 [O, K] in the K order ew_gemm_f16's conv modes read:
     [I/64 chunks][taps][64 channels].  `cpad` zero-pads the input channels first (conv_in: 18 -> 64)."""

@@ -199,6 +199,10 @@ ew_status ew_equi2pers(const uint8_t* equi, const float* rot, uint8_t* out, int 
 ew_status ew_resize_aa_u8(const uint8_t* src, uint8_t* tmp, uint8_t* dst, const int* kk_h, const int* bounds_h, int ksize_h,
                           const int* kk_v, const int* bounds_v, int ksize_v, int V, int Hi, int Wi, int Ho, int Wo, void* stream);
 ew_status ew_u8_hwc_to_f32_chw(const uint8_t* src, float* dst, int V, int H, int W, void* stream);
+/* The 8-bit frame the reference carries between segments: fp32 [V,3,H,W] in [-1,1] -> u8 [V,H,W,3] =
+ * round_half_even(clamp(x/2+0.5, 0, 1)*255), i.e. the pipeline's PIL output (pipeline_evoworld.py:727-732 via diffusers
+ * VideoProcessor) that unified_loop_consistency.py:418-419,432-436 feeds to the next segment and to pano->pers. */
+ew_status ew_f32_chw_to_u8_hwc(const float* src, uint8_t* dst, int V, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

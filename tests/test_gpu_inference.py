@@ -81,9 +81,27 @@ def test_navigator_windows_and_seeding(tiny):
     from evoworld_amd.plucker import ray_c2w_to_plucker
     want1 = ray_c2w_to_plucker(nav.rays, xyz_euler_to_three_by_four_matrix_batch(path[24:49].to(DEV), relative=True))
     assert torch.equal(seen[1][0][0], want1)
-    # same seed per window => a rerun reproduces the window (up to the fp32-atomic order of the GroupNorm statistics)
+    # same seed per window + deterministic kernels => a rerun reproduces the window bit for bit
     g1b = nav.navigate_curve_path(path, img, memorized_images=mem, infer_segment=True, segment_id=1, **kw)
-    assert rel_l2(g1[0][0].cpu(), g1b[0][0].cpu()) < 5e-3   # two realisations of the fp16 rounding-noise floor (~1.5e-3 each)
+    assert torch.equal(g1[0][0], g1b[0][0])
+
+
+def test_navigator_extend_segment_extrapolates_like_reference(tiny):
+    """navigator_evoworld.py:132-172: a 1-pose window steps forward by step_size*position_scale along its yaw, a short
+    window continues with its last xyz increment (rotation held)."""
+    from evoworld_amd.inference import Navigator
+    cfg, pipe = tiny
+    nav = Navigator(pipe, height=128, width=256, num_frames=25)
+    one = torch.tensor([[1.0, 0.0, 2.0, 0.0, 30.0, 0.0]])
+    ext = nav.extend_segment(one, 4)
+    dx, dz = 0.4 * np.sin(np.deg2rad(30.0)) * 0.1, 0.4 * np.cos(np.deg2rad(30.0)) * 0.1
+    want = torch.tensor([[1 + dx * i, 0, 2 + dz * i, 0, 30, 0] for i in range(4)], dtype=torch.float32)
+    assert torch.allclose(ext, want, atol=1e-6)
+    seg = torch.tensor([[0.0, 0, 0, 0, 10, 0], [0.1, 0, 0.2, 0, 20, 0], [0.3, 0, 0.5, 0, 20, 0]])
+    ext = nav.extend_segment(seg, 6)
+    assert ext.shape == (6, 6) and torch.allclose(ext[3:], torch.tensor([[0.5, 0, 0.8, 0, 20, 0], [0.7, 0, 1.1, 0, 20, 0], [0.9, 0, 1.4, 0, 20, 0]]), atol=1e-6)
+    with pytest.raises(AssertionError):
+        nav.extend_segment(seg[:2], 5)                 # last two rotations differ: the reference asserts
 
 
 def test_process_episode_on_device_chain(tiny):
@@ -125,15 +143,34 @@ def test_process_episode_on_device_chain(tiny):
     loop = UnifiedLoopConsistencyPipeline(pipe, depth_model, frames_from_latents, height=H, width=W, num_frames=T, num_segments=2,
                                           num_inference_steps=1, pano_size=(64, 128), face_res=32)
     start = torch.rand(3, H, W, generator=g).to(DEV) * 2 - 1
-    frames = loop.process_episode(start, cam, image_latents_fn)
+    seen_pl = []
+    orig_call = pipe.__class__.__call__
+
+    def spy(self, image, **k):
+        seen_pl.append(k["plucker_embedding"].clone())
+        return orig_call(self, image, **k)
+    pipe.__class__.__call__ = spy
+    try:
+        frames = loop.process_episode(start, cam, image_latents_fn)
+    finally:
+        pipe.__class__.__call__ = orig_call
     assert frames.shape == (49, 3, H, W) and torch.isfinite(frames).all()
+    # every generated frame lives on the 8-bit grid (the reference's PIL frames), and the Navigator / Plücker path saw the
+    # poses with xyz * pos_scale (dataset/CameraTrajDataset.py:348) while yaws / alignment use the unscaled ones
+    lv = (frames / 2 + 0.5) * 255
+    assert float((lv - lv.round()).abs().max()) < 1e-3 and loop.last_frames_u8.dtype == torch.uint8
+    from evoworld_amd.geometry import xyz_euler_to_three_by_four_matrix_batch as _c2w
+    from evoworld_amd.plucker import ray_c2w_to_plucker as _pl
+    scaled = torch.tensor(cam, dtype=torch.float32, device=DEV)
+    scaled[:, :3] *= 0.1
+    assert torch.equal(seen_pl[1][0], _pl(loop.nav.rays, _c2w(scaled[24:49], relative=True)))
     mems = captured["memories"]
     assert len(mems) == 2 and not mems[0].any() and torch.equal(mems[1][0], start)
     # oracle composition of the memory for segment 1 from the same predictions
     from evoworld_amd.geometry import xyz_euler_to_four_by_four_matrix_batch
     from evoworld_amd import ops
     p = captured["preds"]
-    _, yaws = loop.convert_pano_to_pers(frames[:25], cam, 0)
+    _, yaws = loop.convert_pano_to_pers(loop.last_frames_u8[:25], cam, 0)
     temp = cam.copy()
     temp[0:25, 4] = yaws[:25]
     poses = xyz_euler_to_four_by_four_matrix_batch(torch.tensor(temp, dtype=torch.float32), relative=True).numpy()
@@ -171,3 +208,66 @@ def test_cli_entry_point_two_segments(tmp_path):
                     "--num_segments", "2", "--num_inference_steps", "1", "--height", "128", "--width", "256", "--save_frames", "--curve_path"])
     assert rep == [{"episode": "case_000", "frames": 49, "seconds": rep[0]["seconds"], "rank": 0}]
     assert len(os.listdir(tmp_path / "out" / "case_000" / "predictions")) == 49
+
+
+def test_cli_single_segment_is_the_reference_single_segment_path(tmp_path, golden_dir):
+    """BASELINE configs[0] plumbing: `--single_segment` (run_single_segment.sh) on a case_000-shaped episode must take the
+    reference's path (unified_loop_consistency.py:513-535 -> forward_evoworld.process_batch): the episode's LAST 25 poses,
+    Unity->RDF flip, positions x 0.1, pre-rendered memory [panorama/001] + rendered_panorama_vggt_open3d/00..23, mask_mem False.
+    The Plücker tensor the pipeline receives is checked against the reference's own output for example/case_000
+    (tests/golden/plucker.npz, pos_scale 0.1: frames 102-126)."""
+    import json, os
+    from safetensors.torch import save_file
+    from evoworld_amd.unet import DEFAULT_CONFIG, random_state_dict
+    from evoworld_amd.pipeline import StableVideoDiffusionPipeline
+    from oracle.unet_ref import tiny_config
+    import unified_loop_consistency as cli
+    gold = np.load(f"{golden_dir}/plucker.npz")
+    cfg = tiny_config()
+    cfg["num_frames"] = 25
+    ck = tmp_path / "ckpt" / "unet"
+    ck.mkdir(parents=True)
+    json.dump({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, open(ck / "config.json", "w"))
+    save_file({k: v.contiguous() for k, v in random_state_dict({**DEFAULT_CONFIG, **cfg}, 0).items()}, str(ck / "diffusion_pytorch_model.safetensors"))
+    ep = tmp_path / "data" / "case_000"
+    (ep / "panorama").mkdir(parents=True)
+    (ep / "rendered_panorama_vggt_open3d").mkdir()
+    with open(ep / "camera_poses.txt", "w") as f:
+        f.write("Frame,PosX,PosY,PosZ,RotX,RotY,RotZ\n")
+        for i, r in enumerate(gold["poses_unity"]):
+            f.write(f"{i + 1}," + ",".join(repr(float(x)) for x in r) + "\n")
+    rng = np.random.default_rng(0)
+    imgs = {}
+    for i in [1] + list(range(102, 127)):
+        imgs[i] = rng.integers(0, 256, size=(36, 64, 3), dtype=np.uint8)
+        Image.fromarray(imgs[i]).save(ep / "panorama" / f"{i:03}.png")
+    renders = [rng.integers(0, 256, size=(50, 100, 3), dtype=np.uint8) for _ in range(24)]
+    for i, r in enumerate(renders):
+        Image.fromarray(r).save(ep / "rendered_panorama_vggt_open3d" / f"{i:02}.png")
+    seen = {}
+    orig = StableVideoDiffusionPipeline.__call__
+
+    def spy(self, image, **k):
+        seen.update(image=image.clone(), plucker=k["plucker_embedding"].clone(), mask_mem=k["mask_mem"],
+                    memory=k["memorized_pixel_values"].clone(), kw={x: k[x] for x in ("decode_chunk_size", "motion_bucket_id", "fps", "noise_aug_strength")})
+        return orig(self, image, **k)
+    StableVideoDiffusionPipeline.__call__ = spy
+    try:
+        rep = cli.main(["--unet_path", str(tmp_path / "ckpt"), "--base_folder", str(tmp_path / "data" / "case_000"), "--save_dir", str(tmp_path / "out"),
+                        "--num_inference_steps", "1", "--save_frames", "--curve_path", "--single_segment"])
+    finally:
+        StableVideoDiffusionPipeline.__call__ = orig
+    assert rep[0]["frames"] == 25 and rep[0]["mode"] == "single_segment"
+    assert seen["mask_mem"] is False and seen["kw"] == dict(decode_chunk_size=8, motion_bucket_id=127, fps=7, noise_aug_strength=0.02)
+    pl = seen["plucker"][0].cpu().numpy()
+    assert pl.shape == (25, 6, 72, 128)
+    np.testing.assert_allclose(pl[[0, 12, 24]], gold["plucker_ps01_f0_12_24"], atol=3e-6)
+    np.testing.assert_allclose(pl.astype(np.float64).sum(axis=(2, 3)), gold["plucker_ps01_rowsum"], rtol=0, atol=2e-2)
+    # first frame = panorama/102, memory = [panorama/001] + the 24 pre-rendered panoramas, all through the Pillow-exact resize
+    def px(a):
+        return (torch.tensor(np.array(Image.fromarray(a).resize((1024, 576), Image.BILINEAR))).permute(2, 0, 1).float() / 255) * 2 - 1
+    assert torch.equal(seen["image"][0].cpu(), px(imgs[102]))
+    assert seen["memory"].shape == (1, 25, 3, 576, 1024)
+    assert torch.equal(seen["memory"][0, 0].cpu(), px(imgs[1])) and torch.equal(seen["memory"][0, 24].cpu(), px(renders[23]))
+    assert len(os.listdir(tmp_path / "out" / "case_000" / "predictions")) == 25
+    assert len(os.listdir(tmp_path / "out" / "case_000" / "predictions_gt")) == 25

@@ -45,20 +45,9 @@ def parse_arguments(argv=None):
 
 
 def load_camera_poses(episode_path):
-    """camera_poses.txt: 'Frame,PosX,PosY,PosZ,RotX,RotY,RotZ' rows -> [P,6] in the OpenCV convention
-    (unified_loop_consistency.py:370-395)."""
-    from evoworld_amd.geometry import UNITY_TO_OPENCV
-    f = os.path.join(episode_path, "camera_poses.txt")
-    if not os.path.isfile(f):
-        raise FileNotFoundError(f"camera_poses.txt not found under {episode_path}")
-    rows = []
-    for line in open(f):
-        parts = [s.strip() for s in line.strip().split(",")]
-        if len(parts) >= 7 and "rame" not in parts[0]:
-            rows.append([float(x) for x in parts[1:7]])
-    if not rows:
-        raise ValueError(f"No valid camera pose rows parsed from {f}")
-    return np.asarray(rows, dtype=float) * np.asarray(UNITY_TO_OPENCV, dtype=float)
+    """camera_poses.txt -> [P,6] UNSCALED poses in the OpenCV convention (unified_loop_consistency.py:370-395)."""
+    from evoworld_amd.dataset import load_camera_poses as _load
+    return _load(episode_path)
 
 
 def list_episodes(base_folder):
@@ -72,29 +61,84 @@ def list_episodes(base_folder):
                   if os.path.isfile(os.path.join(base_folder, d, "camera_poses.txt")))
 
 
-def load_start_image(episode_path, height, width, device):
-    """panorama/001.png -> float [3,H,W] in [-1,1] (Resize + ToTensor + CustomRescale of the reference dataset)."""
-    f = os.path.join(episode_path, "panorama", "001.png")
-    if os.path.isfile(f):
-        from PIL import Image
-        from evoworld_amd import reprojection as RP
-        u8 = torch.tensor(np.array(Image.open(f).convert("RGB"))).to(device)
-        return RP.memory_to_pixel_values(u8[None], height, width)[0]
-    g = torch.Generator().manual_seed(0)
-    return (torch.rand(3, height, width, generator=g) * 2 - 1).to(device)
-
-
 def synthetic_episode(n_poses=80):
     i = np.arange(n_poses, dtype=np.float64)
     return np.stack([0.04 * i * np.sin(i / 9), 0 * i, 0.04 * i * np.cos(i / 9), 0 * i, 95 + 3.6 * i, 0 * i], 1)
 
 
+def _save_frames_u8(u8_hwc, d, start=0):
+    from PIL import Image
+    os.makedirs(d, exist_ok=True)
+    for i, f in enumerate(u8_hwc.cpu().numpy()):
+        Image.fromarray(f).save(os.path.join(d, f"{i + start + 1:03}.png"))
+
+
+def run_single_segment(args, ep, pipe, unet, dev, out_dir, synthetic):
+    """The reference's single-segment fast path (`run_single_segment`, unified_loop_consistency.py:513-535): the dataset in
+    'reprojection' mode hands out the episode's LAST 25 frames / poses (positions x pos_scale) with the PRE-RENDERED memory
+    panoramas [panorama/001.png] + rendered_panorama_vggt_open3d/*.png, and the batch goes through forward_evoworld.process_batch
+    with mask_mem=False.  Counterparts: evoworld_amd.dataset.load_single_segment_batch -> evoworld_amd.inference.process_batch."""
+    from evoworld_amd import ops
+    from evoworld_amd.dataset import load_single_segment_batch
+    from evoworld_amd.inference import process_batch
+    from evoworld_amd.plucker import equirectangular_to_ray
+    from evoworld_amd.stages import load_stages
+    if synthetic:
+        cam = synthetic_episode(max(args.num_frames, 25))
+        traj = torch.tensor(cam[-args.num_frames:], dtype=torch.float32)
+        traj[:, :3] *= 0.1
+        g = torch.Generator().manual_seed(0)
+        pix = (torch.rand(args.num_frames, 3, args.height, args.width, generator=g) * 2 - 1).to(dev)
+        batch = {"pixel_values": pix[None], "cam_traj": traj[None], "memorized_pixel_values": torch.zeros_like(pix)[None]}
+    else:
+        cam = load_camera_poses(ep)
+        batch = load_single_segment_batch(ep, args.height, args.width, dev, sequence_length=args.num_frames)
+    stages = load_stages(args.stages, args, cross_attention_dim=unet._cfg["cross_attention_dim"], camera_params=cam)
+    rays = torch.tensor(equirectangular_to_ray(args.height // 8, args.width // 8)).float().to(dev)
+    args.mask_mem = False                                                                   # :532
+    cond = stages.image_latents_fn(batch["pixel_values"][0, 0], batch["memorized_pixel_values"][0])
+    torch.cuda.synchronize()
+    t0 = time.time()
+    latents = process_batch(batch, args, pipe, rays, torch.float32, None, os.path.basename(ep), output_type="latent",
+                            num_inference_steps=args.num_inference_steps, **cond)
+    frames_u8 = ops.f32_chw_to_u8_hwc(stages.frames_from_latents(latents).float().contiguous())
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    if args.save_frames:
+        _save_frames_u8(frames_u8, os.path.join(out_dir, "predictions"))                  # forward_evoworld.save_frames
+        _save_frames_u8(ops.f32_chw_to_u8_hwc(batch["pixel_values"][0].float().contiguous()), os.path.join(out_dir, "predictions_gt"))
+    return {"episode": os.path.basename(ep), "frames": int(frames_u8.shape[0]), "seconds": round(dt, 3), "mode": "single_segment"}
+
+
+def run_episode(args, ep, pipe, unet, dev, out_dir, synthetic):
+    """N segments with evolving 3D memory (`process_episode`, unified_loop_consistency.py:398-492)."""
+    from evoworld_amd.dataset import load_complete_episode_batch
+    from evoworld_amd.inference import UnifiedLoopConsistencyPipeline
+    from evoworld_amd.stages import load_stages
+    cam = synthetic_episode(24 * args.num_segments + 8) if synthetic else load_camera_poses(ep)     # UNSCALED
+    stages = load_stages(args.stages, args, cross_attention_dim=unet._cfg["cross_attention_dim"], camera_params=cam)
+    start = None if synthetic else load_complete_episode_batch(ep, args.height, args.width, dev, cam=cam)["first_frame"]
+    if start is None:
+        g = torch.Generator().manual_seed(0)
+        start = (torch.rand(3, args.height, args.width, generator=g) * 2 - 1).to(dev)
+    loop = UnifiedLoopConsistencyPipeline(pipe, stages.depth_model, stages.frames_from_latents, height=args.height,
+                                          width=args.width, num_frames=args.num_frames, num_segments=args.num_segments,
+                                          num_inference_steps=args.num_inference_steps)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    # the unscaled poses go in; process_episode derives the pos-scaled Navigator / Plücker path itself (pos_scale = 0.1)
+    frames = loop.process_episode(start, cam, stages.image_latents_fn, save_dir=out_dir if args.save_frames else None)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    if args.save_frames:
+        _save_frames_u8(loop.last_frames_u8, os.path.join(out_dir, "predictions"))
+    return {"episode": os.path.basename(ep), "frames": int(frames.shape[0]), "seconds": round(dt, 3)}
+
+
 def main(argv=None):
     args = parse_arguments(argv)
     from evoworld_amd import distributed as D
-    from evoworld_amd.inference import UnifiedLoopConsistencyPipeline
     from evoworld_amd.pipeline import StableVideoDiffusionPipeline
-    from evoworld_amd.stages import load_stages
     from evoworld_amd.unet import UNetSpatioTemporalConditionModel
 
     rank, world, local = D.init()
@@ -118,29 +162,15 @@ def main(argv=None):
     report = []
     for idx in mine:
         ep = episodes[idx]
-        cam = synthetic_episode(24 * args.num_segments + 8) if synthetic else load_camera_poses(ep)
-        stages = load_stages(args.stages, args, cross_attention_dim=unet._cfg["cross_attention_dim"], camera_params=cam)
-        start = load_start_image(ep, args.height, args.width, dev)
-        n_seg = 1 if args.single_segment else args.num_segments
-        loop = UnifiedLoopConsistencyPipeline(pipe, stages.depth_model, stages.frames_from_latents, height=args.height,
-                                              width=args.width, num_frames=args.num_frames, num_segments=n_seg,
-                                              num_inference_steps=args.num_inference_steps)
         out_dir = os.path.join(args.save_dir, os.path.basename(ep.rstrip("/")))
         os.makedirs(out_dir, exist_ok=True)
-        torch.cuda.synchronize()
-        t0 = time.time()
-        frames = loop.process_episode(start, cam, stages.image_latents_fn, save_dir=out_dir if args.save_frames else None)
-        torch.cuda.synchronize()
-        dt = time.time() - t0
-        if args.save_frames:
-            from PIL import Image
-            d = os.path.join(out_dir, "predictions")
-            os.makedirs(d, exist_ok=True)
-            u8 = ((frames / 2 + 0.5).clamp(0, 1) * 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
-            for i, f in enumerate(u8):
-                Image.fromarray(f).save(os.path.join(d, f"{i + 1:03}.png"))
-        report.append({"episode": os.path.basename(ep), "frames": int(frames.shape[0]), "seconds": round(dt, 3), "rank": rank})
-        print(json.dumps(report[-1]), flush=True)
+        if args.single_segment:
+            rec = run_single_segment(args, ep, pipe, unet, dev, out_dir, synthetic)
+        else:
+            rec = run_episode(args, ep, pipe, unet, dev, out_dir, synthetic)
+        rec["rank"] = rank
+        report.append(rec)
+        print(json.dumps(rec), flush=True)
     D.barrier()
     D.shutdown()
     return report
