@@ -12,14 +12,15 @@ from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libevoworld_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol declared in include/evoworld_hip.h
 SYMBOLS = [
     "ew_abi_version", "ew_last_error", "ew_gemm_f16", "ew_set_gemm_generation", "ew_get_gemm_generation", "ew_set_gemm_debug", "ew_gemm_last_kernel", "ew_groupnorm_workspace_floats", "ew_groupnorm_stats_f16", "ew_groupnorm_finalize", "ew_groupnorm_apply_f16",
     "ew_layernorm_f16", "ew_attn_spatial_f16", "ew_attn_temporal_f16", "ew_nchw_f32_to_nhwc_f16",
     "ew_nhwc_f16_to_nchw_f32", "ew_euler_cfg_step", "ew_plucker_embed", "ew_cube2equi_gather",
-    "ew_depth_unproject", "ew_splat_cubemap", "ew_splat_resolve", "ew_equi2pers", "ew_resize_aa_u8",
+    "ew_depth_unproject", "ew_select_workspace_bytes", "ew_select_kth_f32", "ew_filter_compact_workspace_bytes",
+    "ew_filter_compact", "ew_splat_cubemap", "ew_splat_resolve", "ew_equi2pers", "ew_resize_aa_u8",
     "ew_u8_hwc_to_f32_chw", "ew_f32_chw_to_u8_hwc",
 ]
 
@@ -76,10 +77,12 @@ def load():
         "ew_nhwc_f16_to_nchw_f32": [P, P, I, I, I, I, I, P],
         "ew_euler_cfg_step": [P, I, P, P, F, F, P, I, I, I, I, P],
         "ew_plucker_embed": [P, P, P, I, I, I, P],
-        "ew_cube2equi_gather": [P, P, P, I, I, I, I, P],
+        "ew_cube2equi_gather": [P, I, P, P, I, I, I, I, P],
+        "ew_select_kth_f32": [P, c_size_t, c_size_t, P, P, P],
+        "ew_filter_compact": [P, c_size_t, F, P, P, I, ctypes.c_uint, P, P, P, P, P],
         "ew_depth_unproject": [P, P, P, P, I, I, I, P],
         "ew_splat_cubemap": [P, c_size_t, P, P, I, I, F, F, F, F, F, P],
-        "ew_splat_resolve": [P, P, P, I, I, P],
+        "ew_splat_resolve": [P, P, I, P, I, I, I, P],
         "ew_equi2pers": [P, P, P, I, I, I, I, I, F, P],
         "ew_resize_aa_u8": [P, P, P, P, P, I, P, P, I, I, I, I, I, I, P],
         "ew_u8_hwc_to_f32_chw": [P, P, I, I, I, P],
@@ -87,6 +90,10 @@ def load():
     }
     lib.ew_groupnorm_workspace_floats.argtypes = [c_int, c_int, c_int, c_int]
     lib.ew_groupnorm_workspace_floats.restype = c_size_t
+    lib.ew_select_workspace_bytes.argtypes = []
+    lib.ew_select_workspace_bytes.restype = c_size_t
+    lib.ew_filter_compact_workspace_bytes.argtypes = [c_size_t]
+    lib.ew_filter_compact_workspace_bytes.restype = c_size_t
     lib.ew_set_gemm_generation.argtypes = [c_int]
     lib.ew_set_gemm_generation.restype = None
     lib.ew_get_gemm_generation.restype = c_int

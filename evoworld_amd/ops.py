@@ -218,13 +218,41 @@ def plucker_embed(rays, c2w):
 
 
 def cube2equi_gather(faces, lut, H, W):
-    """faces uint8 [V,6,res,res,3] (order right,left,bottom,top,front,back), lut int16 [H,W,3] -> uint8 [V,H,W,3]."""
+    """faces uint8 [V,6,res,res,3|4] (order right,left,bottom,top,front,back), lut int16 [H,W,3] -> uint8 [V,H,W,3]."""
     lib = _lib.load()
     _req(faces, torch.uint8, "faces"); _req(lut, torch.int16, "lut")
-    V, res = faces.shape[0], faces.shape[2]
+    V, res, ch = faces.shape[0], faces.shape[2], faces.shape[-1]
     pano = torch.empty(V, H, W, 3, dtype=torch.uint8, device=faces.device)
-    _lib.check(lib.ew_cube2equi_gather(_ptr(faces), _ptr(lut), _ptr(pano), V, H, W, res, _stream()), "ew_cube2equi_gather")
+    _lib.check(lib.ew_cube2equi_gather(_ptr(faces), ch, _ptr(lut), _ptr(pano), V, H, W, res, _stream()), "ew_cube2equi_gather")
     return pano
+
+
+def select_kth(x, k):
+    """x fp32 [n] on the device -> fp32 [2] device tensor (x_(k), x_(k+1)) (0-based, ascending): radix select, no sort."""
+    lib = _lib.load()
+    _req(x, torch.float32, "x")
+    ws = torch.empty(lib.ew_select_workspace_bytes() // 4 + 4, dtype=torch.int32, device=x.device)
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    _lib.check(lib.ew_select_kth_f32(_ptr(x), x.numel(), int(k), _ptr(ws), _ptr(out), _stream()), "ew_select_kth_f32")
+    return out
+
+
+def filter_compact(conf, thr, xyz, img, img_nchw_hw=0):
+    """conf fp32 [n], xyz fp32 [n,3], img fp32 [n,3] (or [S,3,hw] planes with img_nchw_hw = hw) ->
+    (xyz_kept [m,3] fp32, rgbx [m,4] uint8 whose first 3 bytes are (img*255) truncated), order preserved."""
+    lib = _lib.load()
+    _req(conf, torch.float32, "conf"); _req(xyz, torch.float32, "xyz"); _req(img, torch.float32, "img")
+    n = conf.numel()
+    dev = conf.device
+    out_xyz = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    out_rgbx = torch.empty(n, 4, dtype=torch.uint8, device=dev)
+    ws = torch.empty(lib.ew_filter_compact_workspace_bytes(n) // 4 + 1, dtype=torch.int32, device=dev)
+    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.ew_filter_compact(_ptr(conf), n, float(thr), _ptr(xyz), _ptr(img), 1 if img_nchw_hw else 0,
+                                     int(img_nchw_hw), _ptr(out_xyz), _ptr(out_rgbx), _ptr(ws), _ptr(total), _stream()),
+               "ew_filter_compact")
+    m = int(total.item())
+    return out_xyz[:m], out_rgbx[:m]
 
 
 def depth_unproject(depth, extr, intr):
@@ -237,16 +265,24 @@ def depth_unproject(depth, extr, intr):
     return xyz
 
 
-def splat_cubemap(xyz, rgb, w2c, res, fx, fy, cx, cy, z_near):
-    """xyz [N,3] f32, rgb [N,3] u8, w2c [V,6,3,4] f32 -> faces u8 [V,6,res,res,3], zbuf u64-as-int64 [V,6,res,res]."""
+def splat_cubemap(xyz, rgb, w2c, res, fx, fy, cx, cy, z_near, face_channels=3):
+    """xyz [N,3] f32, rgb u8 [N,3] (packed) or [N,4] (RGBX words, possibly a [:, :3] view of one), w2c [V,6,3,4] f32 ->
+    faces u8 [V,6,res,res,face_channels], zbuf u64-as-int64 [V,6,res,res]."""
     lib = _lib.load()
-    _req(xyz, torch.float32, "xyz"); _req(rgb, torch.uint8, "rgb"); _req(w2c, torch.float32, "w2c")
+    _req(xyz, torch.float32, "xyz"); _req(w2c, torch.float32, "w2c")
+    if rgb.dtype != torch.uint8 or rgb.device.type != "cuda":
+        raise TypeError("rgb must be a uint8 device tensor")
+    if rgb.ndim == 2 and rgb.stride(0) == 4 and rgb.stride(1) == 1:
+        stride = 4                                                     # RGBX words (ew_filter_compact output)
+    else:
+        rgb, stride = rgb.contiguous(), 3
     V = w2c.shape[0]
     zbuf = torch.full((V, 6, res, res), -1, dtype=torch.int64, device=xyz.device)  # 0xFFFF... as u64
     _lib.check(lib.ew_splat_cubemap(_ptr(xyz), xyz.shape[0], _ptr(w2c), _ptr(zbuf), V, res, fx, fy, cx, cy, z_near,
                                     _stream()), "ew_splat_cubemap")
-    faces = torch.empty(V, 6, res, res, 3, dtype=torch.uint8, device=xyz.device)
-    _lib.check(lib.ew_splat_resolve(_ptr(zbuf), _ptr(rgb), _ptr(faces), V, res, _stream()), "ew_splat_resolve")
+    faces = torch.empty(V, 6, res, res, face_channels, dtype=torch.uint8, device=xyz.device)
+    _lib.check(lib.ew_splat_resolve(_ptr(zbuf), _ptr(rgb), stride, _ptr(faces), face_channels, V, res, _stream()),
+               "ew_splat_resolve")
     return faces, zbuf
 
 

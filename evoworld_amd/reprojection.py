@@ -149,24 +149,35 @@ def _dev(x, device, dtype=None):
     return t.to(device=device, dtype=dtype) if dtype is not None else t.to(device)
 
 
-def percentile_threshold(conf_flat, q):
-    """np.percentile(conf, q) (method 'linear') for a float32 tensor: the two neighbouring order statistics are selected
-    on the device (torch.kthvalue, exact), the interpolation replays numpy's own float32 arithmetic (numpy >= 2:
-    q / float32(100), virtual index and gamma in float32, _lerp with the t >= 0.5 form) -- verified equal to
-    np.percentile on this stack by tests/test_cpu_reprojection_host.py."""
-    n = conf_flat.numel()
+def percentile_rank(n, q):
+    """(lo, hi, t): np.percentile's 'linear' virtual index (n-1)*q/100 in numpy >= 2 float32 arithmetic -> the two
+    neighbouring order statistics and the interpolation weight."""
     qq = np.true_divide(q, np.float32(100))
     k = (n - 1) * qq
     lo = int(np.floor(k))
     hi = min(lo + 1, n - 1)
-    a = np.float32(torch.kthvalue(conf_flat, lo + 1).values.item())
-    b = np.float32(torch.kthvalue(conf_flat, hi + 1).values.item())
-    t = np.asanyarray(k - lo, dtype=np.float32)
+    return lo, hi, np.asanyarray(k - lo, dtype=np.float32)
+
+
+def percentile_lerp(a, b, t):
+    """numpy's _lerp in float32: a + (b-a)*t, with the t >= 0.5 form b - (b-a)*(1-t)."""
+    a, b = np.float32(a), np.float32(b)
     d = b - a
     r = a + d * t
     if t >= 0.5:
         r = b - d * (1 - t)
     return np.float32(r)
+
+
+def percentile_threshold(conf_flat, q):
+    """np.percentile(conf, q) (method 'linear') for a float32 device tensor: the two neighbouring order statistics are
+    selected on the device (ew_select_kth_f32: radix select, exact), the interpolation replays numpy's own float32
+    arithmetic (`percentile_rank` / `percentile_lerp`, verified equal to np.percentile on this stack by
+    tests/test_cpu_reprojection_host.py; the device selection by tests/test_gpu_reprojection.py)."""
+    n = conf_flat.numel()
+    lo, hi, t = percentile_rank(n, q)
+    ab = ops.select_kth(conf_flat.contiguous(), lo).cpu().numpy()      # x_(lo), x_(lo+1)
+    return percentile_lerp(ab[0], ab[1] if hi > lo else ab[0], t)
 
 
 class PointCloudProcessor:
@@ -194,16 +205,16 @@ class PointCloudProcessor:
                 pts, conf, images = pts[idx:idx + 1], conf[idx:idx + 1], images[idx:idx + 1]
             except (ValueError, IndexError):
                 pass
-        cols = images.permute(0, 2, 3, 1) if (images.ndim == 4 and images.shape[1] == 3) else images
-        cols = (cols.reshape(-1, 3) * 255).to(torch.uint8)                       # truncation, like .astype(np.uint8)
-        cf = conf.reshape(-1)
+        cf = conf.reshape(-1).contiguous()
         thr = 0.0 if conf_thres == 0.0 else float(percentile_threshold(cf, conf_thres))
-        keep = torch.nonzero(cf >= thr).squeeze(1)                               # order-preserving compaction
-        if keep.numel() == 0:
+        # colours = (images NHWC * 255) truncated to uint8 (:286-292), fused into the order-preserving compaction
+        nchw = images.ndim == 4 and images.shape[1] == 3
+        hw = images.shape[2] * images.shape[3] if nchw else 0
+        v, rgbx = ops.filter_compact(cf, thr, pts.reshape(-1, 3).contiguous(), images.contiguous(), hw)
+        c = rgbx[:, :3]                                                          # view of the RGBX words
+        if v.shape[0] == 0:
             v = torch.tensor([[1.0, 0.0, 0.0]], device=dev)
             c = torch.tensor([[255, 255, 255]], dtype=torch.uint8, device=dev)
-        else:
-            v, c = pts.reshape(-1, 3)[keep].contiguous(), cols[keep].contiguous()
         if mask_black_bg or mask_white_bg:
             m = torch.ones(len(v), dtype=torch.bool, device=dev)
             if mask_black_bg:
@@ -212,6 +223,7 @@ class PointCloudProcessor:
                 m &= ~((c[:, 0] > 240) & (c[:, 1] > 240) & (c[:, 2] > 240))
             if m.any():
                 v, c = v[m].contiguous(), c[m].contiguous()
+        v = v.contiguous()
         lo = torch.quantile(v[:: max(1, len(v) // 2_000_000)].double(), 0.05, dim=0)
         hi = torch.quantile(v[:: max(1, len(v) // 2_000_000)].double(), 0.95, dim=0)
         return v, c, float((hi - lo).norm())
@@ -223,16 +235,16 @@ class CubemapRenderer:
     def __init__(self, face_res=512, z_near=Z_NEAR):
         self.face_res, self.z_near = face_res, z_near
 
-    def render_cubemaps(self, vertices, colors, target_extrinsic):
+    def render_cubemaps(self, vertices, colors, target_extrinsic, face_channels=3):
         res = self.face_res
         f = res / (2 * math.tan(math.radians(90.0) / 2))                         # fx = fy = 256, cx = cy = 256 (:624-627)
         w2c = torch.from_numpy(face_w2c(target_extrinsic)).to(vertices.device)
-        faces, _ = ops.splat_cubemap(vertices, colors, w2c, res, f, f, res / 2, res / 2, self.z_near)
-        return faces                                                             # uint8 [V,6,res,res,3], FACE_ORDER
+        faces, _ = ops.splat_cubemap(vertices, colors, w2c, res, f, f, res / 2, res / 2, self.z_near, face_channels)
+        return faces                                                             # uint8 [V,6,res,res,3|4], FACE_ORDER
 
     def render_cubemaps_to_panoramas(self, vertices, colors, target_extrinsic, num_target_view=24, outdir=None,
                                      width=2000, height=1000):
-        faces = self.render_cubemaps(vertices, colors, target_extrinsic)
+        faces = self.render_cubemaps(vertices, colors, target_extrinsic, face_channels=4)   # RGBX words: aligned gathers
         lut = build_cube2equi_lut(width, height, self.face_res).to(vertices.device)
         panos = ops.cube2equi_gather(faces, lut, height, width)                   # uint8 [V,H,W,3] on the device
         if outdir:

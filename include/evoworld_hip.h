@@ -27,7 +27,7 @@ typedef int ew_status;
 #define EW_ERR_UNSUPPORTED (-2)
 #define EW_ERR_HIP (-3)
 
-#define EW_ABI_VERSION 2
+#define EW_ABI_VERSION 3
 int ew_abi_version(void);
 const char* ew_last_error(void);
 
@@ -165,10 +165,11 @@ ew_status ew_euler_cfg_step(const void* eps, int ld_eps, float* latents, const f
 ew_status ew_plucker_embed(const float* rays, const float* c2w, float* out, int N, int H, int W, void* stream);
 
 /* Cube -> equirect gather through the integer LUT (face, v, u) int16 [H,W,3]; faces uint8
- * [V,6,res,res,3] (face order right,left,bottom,top,front,back) -> pano uint8 [V,H,W,3].
+ * [V,6,res,res,face_channels] (face order right,left,bottom,top,front,back; 3 = packed RGB, 4 = RGBX words) -> pano uint8
+ * [V,H,W,3].  Four pixels per thread, dword stores; the LUT is decoded once for all V views.
  * Replaces CubemapRenderer.cube_to_equirectangular_cuda, reproject_vggt_open3d_utils.py:542-614. */
-ew_status ew_cube2equi_gather(const uint8_t* faces, const int16_t* lut, uint8_t* pano, int V, int H, int W, int res,
-                              void* stream);
+ew_status ew_cube2equi_gather(const uint8_t* faces, int face_channels, const int16_t* lut, uint8_t* pano, int V, int H,
+                              int W, int res, void* stream);
 
 /* Depth lift: xyz[s,y,x] = R_s^T (K_s^-1 [u,v,1] z - t_s); depth [S,H,W] f32, extr [S,3,4] world->cam,
  * intr [S,3,3] -> xyz [S,H,W,3] f32.  Replaces vggt unproject_depth_map_to_point_map
@@ -176,15 +177,31 @@ ew_status ew_cube2equi_gather(const uint8_t* faces, const int16_t* lut, uint8_t*
 ew_status ew_depth_unproject(const float* depth, const float* extr, const float* intr, float* xyz, int S, int H, int W,
                              void* stream);
 
+/* Percentile filter of the lifted point cloud (PointCloudProcessor.filter_predictions / _apply_confidence_filter,
+ * reproject_vggt_open3d_utils.py:174-222,294-310): np.percentile(conf, q) needs the two order statistics around the
+ * virtual index; ew_select_kth_f32 finds x_(k) and x_(k+1) (0-based, ascending) of n floats by an MSD radix select
+ * (4 histogram passes + 1 tail pass, no sort) and writes them to out2[0..1] (device).  ws: ew_select_workspace_bytes().
+ * ew_filter_compact keeps the points with conf >= thr IN ORDER (boolean-mask semantics): xyz [n,3] f32 -> out_xyz, colours
+ * (images * 255 truncated to uint8, :286-292) -> out_rgbx (one R|G<<8|B<<16 word per point); *total = number kept.
+ * img: [n,3] floats (img_nchw = 0) or [S,3,hw] planes (img_nchw = 1, n = S*hw).  ws: ew_filter_compact_workspace_bytes(n). */
+size_t ew_select_workspace_bytes(void);
+ew_status ew_select_kth_f32(const float* x, size_t n, size_t k, void* ws, float* out2, void* stream);
+size_t ew_filter_compact_workspace_bytes(size_t n);
+ew_status ew_filter_compact(const float* conf, size_t n, float thr, const float* xyz, const float* img, int img_nchw,
+                            unsigned hw, float* out_xyz, unsigned* out_rgbx, void* ws, unsigned* total, void* stream);
+
 /* Point splat into cubemap z-buffers: for view v, face f: p_cam = w2c[v][f] * p; u = fx*x/z+cx, ...;
- * nearest pixel, min depth wins (64-bit atomicMin of depth-bits<<32 | point index), z > near.
- * zbuf: uint64 [V,6,res,res] pre-filled with 0xFF..FF; resolve writes rgb (0 background).
+ * nearest pixel, min depth wins (64-bit atomicMin of depth-bits<<32 | point index -> deterministic winner), z > near.
+ * Every point is read once (16-byte loads) and tested against all V*6 matrices (wave-uniform, in SGPRs); fragments that a
+ * relaxed read of the cell already beats skip the atomic.  zbuf: uint64 [V,6,res,res] pre-filled with 0xFF..FF.
+ * ew_splat_resolve writes the winners' colours (0 background): rgb = packed RGB bytes (rgb_stride 3) or RGBX words
+ * (rgb_stride 4, as ew_filter_compact emits); faces uint8 [V,6,res,res,face_channels] (3 | 4).
  * Replaces Open3D OffscreenRenderer point rendering driven by render_face/render_cubemap,
  * reproject_vggt_open3d_utils.py:617-666 (parity unpinned: Filament GL). */
 ew_status ew_splat_cubemap(const float* xyz, size_t npts, const float* w2c, unsigned long long* zbuf, int V, int res,
                            float fx, float fy, float cx, float cy, float z_near, void* stream);
-ew_status ew_splat_resolve(const unsigned long long* zbuf, const uint8_t* rgb, uint8_t* faces, int V, int res,
-                           void* stream);
+ew_status ew_splat_resolve(const unsigned long long* zbuf, const uint8_t* rgb, int rgb_stride, uint8_t* faces,
+                           int face_channels, int V, int res, void* stream);
 
 /* Equirect -> perspective bilinear gather (pyequilib Equi2Pers restatement; unified_loop_consistency.py:299-334).
  * equi uint8 [F,He,We,3]; rot [F,3,3] f32 (camera->pano rotation); out uint8 [F,Hp,Wp,3]. */

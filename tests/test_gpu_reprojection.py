@@ -132,3 +132,48 @@ class _Small:
 
     def render_cubemaps_to_panoramas(self, v, c, target, n, outdir):
         return self.cr.render_cubemaps_to_panoramas(v, c, target, n, outdir, width=256, height=128)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 1000, 4097, 1_000_003])
+def test_radix_select_and_percentile_match_numpy(n):
+    """ew_select_kth_f32 against a numpy sort (ties, negatives, +-0, denormals), and the full percentile threshold against
+    np.percentile (reproject_vggt_open3d_utils.py:297-310)."""
+    from evoworld_amd import ops
+    from evoworld_amd import reprojection as RP
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal(n).astype(np.float32)
+    if n >= 1000:
+        a[::7] = a[3]                       # heavy ties
+        a[1:50] = 0.0
+        a[51:60] = -0.0
+        a[60:70] = 1e-42                    # denormals
+    srt = np.sort(a)
+    x = torch.tensor(a).to(DEV)
+    for k in sorted({0, n // 2, max(0, n - 2), n - 1, min(n - 1, 17)}):
+        got = ops.select_kth(x, k).cpu().numpy()
+        assert got[0] == srt[k], (n, k)
+        assert got[1] == srt[min(k + 1, n - 1)], (n, k)
+    for q in (50.0, 30.0, 99.5):
+        assert RP.percentile_threshold(x, q) == np.percentile(a, q), (n, q)
+
+
+@pytest.mark.parametrize("nchw", [True, False])
+def test_filter_compact_matches_boolean_mask(nchw):
+    """order-preserving compaction + colour extraction == numpy boolean-mask semantics (:286-310)"""
+    from evoworld_amd import ops
+    S, H, W = 3, 37, 53
+    n = S * H * W
+    g = torch.Generator().manual_seed(0)
+    conf = torch.rand(n, generator=g)
+    conf[::5] = 0.5
+    xyz = torch.randn(n, 3, generator=g)
+    img = torch.rand(S, 3, H, W, generator=g)
+    img[0, :, 0, :4] = torch.tensor([0.0, 1.0, 0.999999, 0.5])[None]
+    thr = 0.5
+    imgs = img if nchw else img.permute(0, 2, 3, 1).contiguous()
+    v, rgbx = ops.filter_compact(conf.to(DEV), thr, xyz.to(DEV), imgs.to(DEV), H * W if nchw else 0)
+    keep = conf.numpy() >= np.float32(thr)
+    cols = (img.permute(0, 2, 3, 1).reshape(-1, 3).numpy() * 255).astype(np.uint8)
+    assert v.shape[0] == int(keep.sum())
+    assert np.array_equal(v.cpu().numpy(), xyz.numpy()[keep])
+    assert np.array_equal(rgbx[:, :3].cpu().numpy(), cols[keep])
