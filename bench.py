@@ -24,6 +24,17 @@ ALGO_TFLOP_PER_FORWARD = 154.31      # SURVEY.md §8d, config 2, dead cross-atte
 PEAK_F16_DENSE_TFLOPS = 2500.0       # MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16 MFMA
 
 
+def committed_traffic():
+    """HBM bytes of ONE U-Net forward from the committed rocprofv3 PMC run (profiles/r02_hbm_traffic.json: separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.sh).
+    It is a recorded measurement of this code, not a live one: PMC collection needs its own profiler passes."""
+    f = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    try:
+        return json.load(open(f))
+    except (OSError, ValueError):
+        return None
+
+
 def synth_inputs(T, h, w, seed, device):
     """SURVEY.md §8d config 2 synthetic clip (seeded on CPU so that RNG differences between stacks vanish)."""
     from evoworld_amd.geometry import xyz_euler_to_three_by_four_matrix_batch
@@ -41,15 +52,17 @@ def synth_inputs(T, h, w, seed, device):
     return latents.to(device), image_latents.to(device), ehs.to(device), plucker
 
 
-def cpu_baseline(max_threads=32):
+def cpu_baseline(max_threads=32, frames=4):
     """The reference's CPU path (diffusers fp32 on PyTorch) restated by the oracle, timed on the host cores on a
-    BOUNDED sample (~15-20 s of CPU work): one full-resolution (72x128 latents) U-Net forward over FOUR frames of ONE CFG row
-    (B=1, T=4, so the temporal convs / temporal attention see more than one frame), incl. the reference's dead
-    cross-attention work.  Per-frame cost is linear in B*T (spatial attention/convs are per frame, the temporal parts are
-    linear in T up to the small T^2 attention term), so a clip step (B=2, T=25) = 12.5 samples.  Threads are capped: torch's CPU convs do
-    not scale past a few dozen threads on this problem (256 threads measured 20x slower than the cap)."""
+    BOUNDED sample (~15-20 s of CPU work): one full-resolution (72x128 latents) U-Net forward over `frames` frames of ONE CFG
+    row (B=1, T=4, so the temporal convs / temporal attention see more than one frame), incl. the reference's dead
+    cross-attention work, scaled linearly to a clip step (B=2, T=25 = 50 frames).  The extrapolation error was measured once
+    against a COMPLETE full-size CPU forward (`bench.py --cpu-baseline-full`).  `cores` = the threads
+    used (torch's CPU convs do not scale past a few dozen threads on this problem: 256 threads measured 20x slower than 32);
+    `host_cores` = os.cpu_count()."""
     from oracle.unet_ref import UNetSpatioTemporalConditionModelRef
-    cores = min(os.cpu_count() or 1, max_threads)
+    host = os.cpu_count() or 1
+    cores = min(host, max_threads)
     torch.set_num_threads(cores)
     with torch.device("meta"):
         m = UNetSpatioTemporalConditionModelRef()
@@ -58,18 +71,21 @@ def cpu_baseline(max_threads=32):
         for p in m.parameters():
             p.fill_(0.01)                      # timing only: values do not matter, denormals/NaNs must be avoided
     g = torch.Generator().manual_seed(0)
-    TS = 4
-    x = torch.randn(1, TS, 18, 72, 128, generator=g)
-    ehs = torch.randn(1, 1, 1024, generator=g)
-    ids = torch.tensor([[6.0, 127.0, 0.02]])
+    full = frames >= 50
+    B, TS = (2, 25) if full else (1, frames)
+    x = torch.randn(B, TS, 18, 72, 128, generator=g)
+    ehs = torch.randn(B, 1, 1024, generator=g)
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * B)
     t0 = time.time()
     m(x, torch.tensor(1.0), ehs, ids, exec_dead_cross_attn=True)
     dt = time.time() - t0
-    t_forward = dt * 50.0 / TS
+    t_forward = dt * 50.0 / (B * TS)
     fps = 25.0 / (25 * t_forward)
-    return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 fp32 oracle U-Net forward at 72x128 latents over B=1 x T={TS} frames ({dt:.1f} s on {cores} threads), "
-                      f"scaled x{50 / TS:g} to B=2,T=25 and x25 denoise steps per clip"}
+    what = (f"1 COMPLETE fp32 oracle U-Net forward (B=2, T=25 at 72x128 latents: {dt:.1f} s on {cores} threads)" if full else
+            f"1 fp32 oracle U-Net forward at 72x128 latents over B=1 x T={TS} frames ({dt:.1f} s on {cores} threads), "
+            f"scaled x{50 / TS:g} to B=2,T=25")
+    return {"value": fps, "unit": "frames/s", "cores": cores, "host_cores": host, "kind": "port",
+            "sample": what + " and x25 denoise steps per clip (steps are shape-identical)"}
 
 
 def kernel_breakdown(unet, pipe, latents, image_latents, ehs, plucker, T, h, w, top=8):
@@ -153,15 +169,34 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--denoise-steps", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="time ONE complete full-size CPU forward (minutes) instead of the bounded sample")
     ap.add_argument("--tiny", action="store_true", help="shrunken U-Net (plumbing check only; result flagged invalid)")
     args = ap.parse_args()
 
+    # --gpus N from a plain `python bench.py`: re-exec as N ranks (one process per GPU) under torch.distributed.run
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {have} device(s) answer")
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}")
     from evoworld_amd import distributed as D
     rank, world, local = D.init()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"rank {rank}: local device {local} does not exist ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -173,7 +208,24 @@ def main():
     if args.tiny:
         cfg = dict(block_out_channels=(64, 128, 256, 256), addition_time_embed_dim=64,
                    projection_class_embeddings_input_dim=192, cross_attention_dim=1024, num_attention_heads=(1, 2, 4, 4))
-    unet = UNetSpatioTemporalConditionModel.from_random(seed=0, device=dev, **cfg)
+    # rank 0 owns the weights (random-init here, a checkpoint in production); the other ranks receive the packed 3 GB over
+    # RCCL / xGMI once (north_star: "RCCL broadcast"), then every rank runs its own clips with no collective in the loop
+    if rank == 0:
+        unet = UNetSpatioTemporalConditionModel.from_random(seed=0, device=dev, **cfg)
+    else:
+        unet = UNetSpatioTemporalConditionModel.from_zeros(device=dev, **cfg)
+    if world > 1 or os.environ.get("EW_FORCE_DIST") == "1":
+        torch.cuda.synchronize()
+        t_b = time.perf_counter()
+        unet.broadcast_weights(src=0)
+        torch.cuda.synchronize()
+        t_b = time.perf_counter() - t_b
+        cs = unet.weights_checksum()
+        lo, hi = D.max_over_ranks(-cs, dev), D.max_over_ranks(cs, dev)
+        if -lo != hi:
+            raise SystemExit(f"weight broadcast mismatch: checksum range [{-lo}, {hi}]")
+        if rank == 0:
+            print(f"[bench] weight broadcast to {world} rank(s): {t_b * 1e3:.1f} ms, checksum {cs:.6e} on every rank", file=sys.stderr)
     pipe = StableVideoDiffusionPipeline(unet=unet, scheduler=EulerDiscreteScheduler())
     T, h, w = args.frames, args.height // 8, args.width // 8
     latents, image_latents, ehs, plucker = synth_inputs(T, h, w, seed=10 + rank, device=dev)
@@ -218,6 +270,7 @@ def main():
         fw_ms = sum(s.elapsed_time(e) for s, e in fw_events) / max(1, len(fw_events))
         full = (not args.tiny) and (T, args.height, args.width, args.denoise_steps) == (25, 576, 1024, 25)
         ach = ALGO_TFLOP_PER_FORWARD / (fw_ms / 1e3) if full else None
+        tr = committed_traffic()
         line = {
             "metric": "panoramic frames/sec per clip (576x1024x25f, 25 denoise steps)",
             "value": world * T * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -228,12 +281,13 @@ def main():
                        "unet_forward_ms": fw_ms, "valid": bool(full and finite)},
             "roofline": {"bound": "mfma", "kernel": "U-Net denoise step (all launches of one forward, HIP events on the launch stream)",
                          "achieved": ach, "peak": PEAK_F16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (ach / PEAK_F16_DENSE_TFLOPS) if ach else None, "traffic": None,
+                         "frac": (ach / PEAK_F16_DENSE_TFLOPS) if ach else None,
+                         "traffic": (tr or {}).get("bytes_per_forward") if full else None, "traffic_detail": tr,
                          "algorithmic_tflop_per_launch": ALGO_TFLOP_PER_FORWARD,
                          "kernels": kernels},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(frames=50 if args.cpu_baseline_full else 4)
         print(json.dumps(line), flush=True)
     D.barrier()
     D.shutdown()

@@ -253,6 +253,45 @@ class UNetSpatioTemporalConditionModel:
         m.load_state_dict(random_state_dict(m._cfg, seed), device=device)
         return m
 
+    @classmethod
+    def from_zeros(cls, device="cuda", **config):
+        """Same packed layout with all-zero weights: what a rank that does NOT read the checkpoint builds before
+        `broadcast_weights` fills it over RCCL."""
+        m = cls(**config)
+        sd = OrderedDict((k, torch.zeros(shape)) for k, (shape, _) in param_spec(m._cfg).items())
+        m.load_state_dict(sd, device=device)
+        return m
+
+    def packed_tensors(self):
+        """Every device tensor of the packed weight set, in a fixed order (3.04 GB fp16 for the full U-Net)."""
+        out = []
+        for k in sorted(self.w, key=str):
+            v = self.w[k]
+            if isinstance(v, dict):
+                out += [v[n] for n in sorted(v) if isinstance(v[n], torch.Tensor)]
+            elif isinstance(v, tuple):
+                out += [t for t in v if isinstance(t, torch.Tensor)]
+            elif isinstance(v, torch.Tensor):
+                out.append(v)
+        return out
+
+    def broadcast_weights(self, src=0):
+        """One-time RCCL broadcast of the packed weights (and the AlphaBlender scalars) from rank `src` (SURVEY.md §8e:
+        the rank that read the checkpoint serves the others over xGMI instead of N disk reads).  No-op single-process."""
+        from . import distributed as D
+        D.broadcast_tensors(self.packed_tensors(), src=src)
+        keys = [k for k in sorted(self.w, key=str) if isinstance(self.w[k], dict) and "mix" in self.w[k]]
+        mix = torch.tensor([self.w[k]["mix"] for k in keys], dtype=torch.float64, device=self.device)
+        D.broadcast_tensors([mix], src=src)
+        for k, v in zip(keys, mix.tolist()):
+            self.w[k]["mix"] = v
+        self._pos_cache = {}
+        return self
+
+    def weights_checksum(self):
+        """fp64 sum of all packed weights (cheap equality check across ranks after the broadcast)."""
+        return float(sum(t.double().sum() for t in self.packed_tensors()))
+
     def requires_grad_(self, _flag=False):
         return self
 

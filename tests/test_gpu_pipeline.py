@@ -163,3 +163,22 @@ def test_input_validation_matches_reference(models):
     with pytest.raises(ValueError):
         pipe(torch.zeros(1, 3, 64, 128), height=64, width=128, num_frames=4, plucker_embedding=pl,
              image_latents=torch.zeros(1, 4, 4, 8, 16), image_embeddings=torch.zeros(1, 1, 64))      # memory frames != T
+
+
+def test_bench_one_rank_over_rccl_broadcasts_weights():
+    """bench.py with the process group forced on (one rank over RCCL): the packed weights go through
+    unet.broadcast_weights -> dist.broadcast and the JSON line reports the rank count it actually ran with."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, EW_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--tiny", "--steps", "1", "--warmup", "0", "--denoise-steps", "2",
+                        "--height", "128", "--width", "256", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "weight broadcast to 1 rank(s)" in r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["valid"] is False and line["value"] > 0

@@ -147,11 +147,22 @@ def main(argv=None):
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
     os.makedirs(args.save_dir, exist_ok=True)
-    if args.random_init:
-        unet = UNetSpatioTemporalConditionModel.from_random(seed=args.seed, device=dev, num_frames=args.num_frames)
+    # rank 0 reads (or draws) the weights; the other ranks receive the packed set once over RCCL / xGMI
+    sub = "unet" if os.path.isdir(os.path.join(args.unet_path, "unet")) else None
+    if rank == 0 or world == 1:
+        if args.random_init:
+            unet = UNetSpatioTemporalConditionModel.from_random(seed=args.seed, device=dev, num_frames=args.num_frames)
+        else:
+            unet = UNetSpatioTemporalConditionModel.from_pretrained(args.unet_path, subfolder=sub, device=dev)
     else:
-        sub = "unet" if os.path.isdir(os.path.join(args.unet_path, "unet")) else None
-        unet = UNetSpatioTemporalConditionModel.from_pretrained(args.unet_path, subfolder=sub, device=dev)
+        cfg = {"num_frames": args.num_frames}
+        cj = os.path.join(args.unet_path, sub or "", "config.json")
+        if not args.random_init and os.path.exists(cj):
+            from evoworld_amd.unet import DEFAULT_CONFIG
+            cfg = {k: (tuple(v) if isinstance(v, list) else v) for k, v in json.load(open(cj)).items() if k in DEFAULT_CONFIG}
+        unet = UNetSpatioTemporalConditionModel.from_zeros(device=dev, **cfg)
+    if world > 1:
+        unet.broadcast_weights(src=0)
     pipe = StableVideoDiffusionPipeline(unet=unet)
 
     episodes = list_episodes(args.base_folder)[args.start_idx: args.start_idx + args.num_data]
