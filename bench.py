@@ -118,8 +118,17 @@ def kernel_breakdown(unet, pipe, latents, image_latents, ehs, plucker, T, h, w, 
                 g = a[0]._obj
                 key = lib.ew_gemm_last_kernel().decode()
                 fl = 2.0 * g.M * g.N * (g.c1 + g.c2) * {0: 1, 1: 9, 2: 3}[g.mode]
+                if os.environ.get("EW_BENCH_BY_SHAPE"):
+                    key += f" M={g.M} N={g.N} K={(g.c1 + g.c2) * {0: 1, 1: 9, 2: 3}[g.mode]}"
             else:
                 key = kname[n]
+                if os.environ.get("EW_BENCH_BY_SHAPE"):
+                    if n == "ew_layernorm_f16":
+                        key += f" rows={a[9]} C={a[10]}"
+                    elif n.startswith("ew_groupnorm") and n != "ew_groupnorm_finalize":
+                        key += f" slabs={a[-9] if n.endswith('apply_f16') else a[3]}"
+                    elif n == "ew_attn_spatial_f16":
+                        key += f" S={a[5]}"
                 if n == "ew_attn_spatial_f16":
                     fl = 4.0 * a[4] * a[6] * a[5] * a[5] * 64          # n_seq * heads * S^2 * head_dim
             rec.append((key, fl, s, e))
