@@ -18,10 +18,11 @@ ABI_VERSION = 3
 SYMBOLS = [
     "ew_abi_version", "ew_last_error", "ew_gemm_f16", "ew_set_gemm_generation", "ew_get_gemm_generation", "ew_set_gemm_debug", "ew_gemm_last_kernel", "ew_groupnorm_workspace_floats", "ew_groupnorm_stats_f16", "ew_groupnorm_finalize", "ew_groupnorm_apply_f16",
     "ew_layernorm_f16", "ew_attn_spatial_f16", "ew_attn_temporal_f16", "ew_nchw_f32_to_nhwc_f16",
-    "ew_nhwc_f16_to_nchw_f32", "ew_euler_cfg_step", "ew_plucker_embed", "ew_cube2equi_gather",
+    "ew_nhwc_f16_to_nchw_f32", "ew_softmax_rows_f16", "ew_time_conv3_f32", "ew_euler_cfg_step", "ew_plucker_embed", "ew_cube2equi_gather",
     "ew_depth_unproject", "ew_select_workspace_bytes", "ew_select_kth_f32", "ew_filter_compact_workspace_bytes",
     "ew_filter_compact", "ew_splat_cubemap", "ew_splat_resolve", "ew_equi2pers", "ew_resize_aa_u8",
-    "ew_u8_hwc_to_f32_chw", "ew_f32_chw_to_u8_hwc",
+    "ew_u8_hwc_to_f32_chw", "ew_f32_chw_to_u8_hwc", "ew_blur_axis_f32", "ew_bicubic_resize_f32", "ew_vit_patchify_f16",
+    "ew_attn_small_f16",
 ]
 
 
@@ -35,7 +36,7 @@ class GemmArgs(ctypes.Structure):
         ("n_img", c_int), ("h_in", c_int), ("w_in", c_int), ("h_out", c_int), ("w_out", c_int),
         ("stride", c_int), ("upsample", c_int), ("tB", c_int), ("tT", c_int), ("tP", c_int),
         ("rows_per_group", c_int), ("act", c_int), ("c_acc", c_float), ("c_r1", c_float), ("c_r2", c_float),
-        ("r1_lo", c_void_p), ("r2_lo", c_void_p), ("out_lo", c_void_p),
+        ("r1_lo", c_void_p), ("r2_lo", c_void_p), ("out_lo", c_void_p), ("conv_shift", c_int),
     ]
 
 
@@ -76,6 +77,8 @@ def load():
         "ew_nchw_f32_to_nhwc_f16": [P, P, I, I, I, I, I, I, F, P],
         "ew_nhwc_f16_to_nchw_f32": [P, P, I, I, I, I, I, P],
         "ew_euler_cfg_step": [P, I, P, P, F, F, P, I, I, I, I, P],
+        "ew_softmax_rows_f16": [P, P, P, LL, I, LL, P],
+        "ew_time_conv3_f32": [P, P, P, P, I, I, I, I, P],
         "ew_plucker_embed": [P, P, P, I, I, I, P],
         "ew_cube2equi_gather": [P, I, P, P, I, I, I, I, P],
         "ew_select_kth_f32": [P, c_size_t, c_size_t, P, P, P],
@@ -87,6 +90,10 @@ def load():
         "ew_resize_aa_u8": [P, P, P, P, P, I, P, P, I, I, I, I, I, I, P],
         "ew_u8_hwc_to_f32_chw": [P, P, I, I, I, P],
         "ew_f32_chw_to_u8_hwc": [P, P, I, I, I, P],
+        "ew_blur_axis_f32": [P, P, I, P, LL, I, I, I, P],
+        "ew_bicubic_resize_f32": [P, P, I, I, I, I, I, I, P, P, P],
+        "ew_vit_patchify_f16": [P, P, I, I, I, I, P],
+        "ew_attn_small_f16": [P, P, P, P, I, I, I, I, I, I, F, P],
     }
     lib.ew_groupnorm_workspace_floats.argtypes = [c_int, c_int, c_int, c_int]
     lib.ew_groupnorm_workspace_floats.restype = c_size_t

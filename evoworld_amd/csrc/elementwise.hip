@@ -63,6 +63,92 @@ __global__ void euler_cfg_kernel(const f16* __restrict__ eps, int ld_eps, float*
 
 inline int grid_for(long long n) { long long b = (n + 255) / 256; return (int)(b < 4096 ? (b > 0 ? b : 1) : 4096); }
 
+// Row softmax of a score matrix carried as split fp16 (hi + lo): p[r][c] = exp(s[r][c] - max_r) / sum_r, fp32 math, fp16 out.
+// One wave per row, the row streams through registers in chunks of 8 columns per lane (two passes over the row: max+sum
+// with the online rescale, then normalise; the second pass re-reads the row from L2).  Used by the VAE's single-head
+// 512-wide attention (S = 9216 keys per frame): scores come from ew_gemm_f16 with out_lo, so nothing is rounded to fp16
+// before the exponential (diffusers Attention upcast_softmax).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* __restrict__ hi, const f16* __restrict__ lo,
+                                                           f16* __restrict__ out, long long rows, int cols, long long ld) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const f16* h = hi + row * ld;
+    const f16* l = lo ? lo + row * ld : nullptr;
+    float m = -INFINITY, sum = 0.f;
+    for (int c = lane * 8; c < cols; c += 512) {
+        const f16x8 a = *(const f16x8*)(h + c);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+        if (l) {
+            const f16x8 b = *(const f16x8*)(l + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)b[e];
+        }
+        float cm = v[0];
+#pragma unroll
+        for (int e = 1; e < 8; ++e) cm = fmaxf(cm, v[e]);
+        const float mn = fmaxf(m, cm);
+        float cs = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs += __expf(v[e] - mn);
+        sum = sum * __expf(m - mn) + cs;
+        m = mn;
+    }
+    const float mw = wave_max(m);
+    sum = wave_sum(sum * __expf(m - mw));
+    const float inv = 1.0f / sum;
+    f16* o = out + row * ld;
+    for (int c = lane * 8; c < cols; c += 512) {
+        const f16x8 a = *(const f16x8*)(h + c);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+        if (l) {
+            const f16x8 b = *(const f16x8*)(l + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)b[e];
+        }
+        f16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (f16)(__expf(v[e] - mw) * inv);
+        *(f16x8*)(o + c) = r;
+    }
+}
+
+// TemporalDecoder.time_conv_out: Conv3d(C, C, (3,1,1), padding (1,0,0)) on fp32 frames [B, T, C, HW] (C <= 4):
+// y[b,t,o,p] = bias[o] + sum_{kt,c} w[o][c][kt] * x[b, t+kt-1, c, p], zero outside [0,T).  4 pixels per thread.
+__global__ __launch_bounds__(256) void time_conv3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int B, int T,
+                                                         int C, int HW) {
+    const int hq = HW / 4;
+    const long long total = (long long)B * T * hq;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int p4 = (int)(i % hq);
+        const long long bt = i / hq;
+        const int t = (int)(bt % T);
+        f32x4 in[3][4];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+            const int tt = t + kt - 1;
+            const bool ok = tt >= 0 && tt < T;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                in[kt][c] = (ok && c < C) ? *(const f32x4*)(x + ((bt + kt - 1) * C + c) * HW + (long long)p4 * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int o = 0; o < C; ++o) {
+            f32x4 acc = {bias[o], bias[o], bias[o], bias[o]};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt)
+                    if (c < C) acc += w[(o * C + c) * 3 + kt] * in[kt][c];
+            *(f32x4*)(y + (bt * C + o) * HW + (long long)p4 * 4) = acc;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" ew_status ew_nchw_f32_to_nhwc_f16(const float* x, void* y, int N, int C, int H, int W, int ldc, int c_off,
@@ -88,4 +174,23 @@ extern "C" ew_status ew_euler_cfg_step(const void* eps, int ld_eps, float* laten
     hipLaunchKernelGGL(euler_cfg_kernel, dim3(grid_for((long long)T * h * w)), dim3(256), 0, (hipStream_t)stream,
                        (const f16*)eps, ld_eps, latents, guidance, sigma, sigma_next, (f16*)next_in, cpad, T, h * w);
     return ew_check_launch("ew_euler_cfg_step");
+}
+
+extern "C" ew_status ew_softmax_rows_f16(const void* hi, const void* lo, void* out, long long rows, int cols, long long ld,
+                                         void* stream) {
+    EW_REQUIRE(hi && out && rows > 0 && cols > 0, "ew_softmax_rows_f16: bad args");
+    EW_REQUIRE(cols % 8 == 0 && ld % 8 == 0 && ld >= cols, "ew_softmax_rows_f16: cols and ld must be multiples of 8");
+    EW_REQUIRE((rows + 3) / 4 < 0x7fffffffLL, "ew_softmax_rows_f16: too many rows");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const f16*)hi,
+                       (const f16*)lo, (f16*)out, rows, cols, ld);
+    return ew_check_launch("ew_softmax_rows_f16");
+}
+
+extern "C" ew_status ew_time_conv3_f32(const float* x, const float* w, const float* bias, float* y, int B, int T, int C, int HW,
+                                       void* stream) {
+    EW_REQUIRE(x && w && bias && y && B > 0 && T > 0 && C > 0 && C <= 4 && HW > 0 && HW % 4 == 0, "ew_time_conv3_f32: need C <= 4, HW %% 4 == 0");
+    long long blocks = ((long long)B * T * (HW / 4) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(time_conv3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, B, T, C, HW);
+    return ew_check_launch("ew_time_conv3_f32");
 }

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
                 const int img = m / hw, rem = m - img * hw;
                 const int oy = rem / p.w_out, ox = rem - oy * p.w_out;
                 const int hlim = p.upsample ? 2 * p.h_in : p.h_in, wlim = p.upsample ? 2 * p.w_in : p.w_in;
-                const int cy = oy * p.stride, cx = ox * p.stride;               // centre tap, in (possibly upsampled) input coords
+                const int cy = oy * p.stride + p.conv_shift, cx = ox * p.stride + p.conv_shift;               // centre tap, in (possibly upsampled) input coords
                 mask = 0;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
@@ -452,6 +452,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
                                 float x = v[e] + (float)bvv[it][e];
                                 if constexpr (RB) x += (float)rbv[set][e];
                                 if (p.act == EW_ACT_SILU) x = ew_silu(x);
+                                else if (p.act == EW_ACT_GELU) x = ew_gelu(x);
                                 x *= p.c_acc;
                                 if constexpr (R1 && LO) x += p.c_r1 * ((float)q1v[set][e] + (float)q1l[set][e]);
                                 else if constexpr (R1) x += p.c_r1 * (float)q1v[set][e];

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                 const int img = m / hw, rem = m - img * hw;
                 const int oy = rem / p.w_out, ox = rem - oy * p.w_out;
                 const int hlim = p.upsample ? 2 * p.h_in : p.h_in, wlim = p.upsample ? 2 * p.w_in : p.w_in;
-                const int cy = oy * p.stride, cx = ox * p.stride;               // centre tap, in (possibly upsampled) input coords
+                const int cy = oy * p.stride + p.conv_shift, cx = ox * p.stride + p.conv_shift;               // centre tap, in (possibly upsampled) input coords
                 mask = 0;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                         if constexpr (R1 && LO) q1l = *(const f16x8*)((const char*)r1lp + (unsigned)(mc * ld1l + n * m1l) * 2u);
                         if constexpr (R2 && LO) q2l = *(const f16x8*)((const char*)r2lp + (unsigned)(mc * ld2l + n * m2l) * 2u);
                     };
-                    const bool silu = p.act == EW_ACT_SILU;
+                    const bool silu = p.act == EW_ACT_SILU, gelu = p.act == EW_ACT_GELU;
                     fetch(0, 0);
 #pragma unroll
                     for (int i = 0; i < FM; ++i) {
@@ -367,6 +367,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                             if (silu) {
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) vv[e] = ew_silu(vv[e]);
+                            } else if (gelu) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) vv[e] = ew_gelu(vv[e]);
                             }
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {

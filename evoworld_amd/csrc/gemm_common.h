@@ -19,6 +19,7 @@ struct GemmP {
     int c1, c2, lda, lda2, ld_out, ld_r1, ld_r2, ld_rowbias;
     int mode, n_img, h_in, w_in, h_out, w_out, stride, upsample;
     int tB, tT, tP;
+    int conv_shift;  // conv3x3: 0 = taps centred on oy*stride (padding 1), 1 = taps start at oy*stride (padding (0,1): diffusers Downsample2D(padding=0))
     int rows_per_group, act;
     float c_acc, c_r1, c_r2;
     int tiles_m, tiles_n;

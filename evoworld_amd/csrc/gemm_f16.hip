@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
                 long long pix;
                 if (p.mode == EW_A_CONV3X3) {
                     const int ky = tap / 3, kx = tap - ky * 3;
-                    int iy = a_y[i] * p.stride + ky - 1, ix = a_x[i] * p.stride + kx - 1;
+                    int iy = a_y[i] * p.stride + ky - 1 + p.conv_shift, ix = a_x[i] * p.stride + kx - 1 + p.conv_shift;
                     const int hlim = p.upsample ? 2 * p.h_in : p.h_in, wlim = p.upsample ? 2 * p.w_in : p.w_in;
                     const bool ok = iy >= 0 && iy < hlim && ix >= 0 && ix < wlim;
                     if (p.upsample) { iy >>= 1; ix >>= 1; }
@@ -199,6 +199,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
                     if (p.act == EW_ACT_SILU) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = ew_silu(v[e]);
+                    } else if (p.act == EW_ACT_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ew_gelu(v[e]);
                     }
                     v *= p.c_acc;
                     if (p.r1) {
@@ -314,6 +317,7 @@ extern "C" ew_status ew_gemm_f16(const ew_gemm_args* a, void* stream) {
                    "ew_gemm_f16: bad conv3x3 geometry");
         EW_REQUIRE((long long)a->n_img * a->h_out * a->w_out == a->M, "ew_gemm_f16: M != n_img*h_out*w_out");
         EW_REQUIRE(!(a->upsample && a->stride != 1), "ew_gemm_f16: upsample needs stride 1");
+        EW_REQUIRE((a->conv_shift == 0 || a->conv_shift == 1) && !(a->conv_shift && a->upsample), "ew_gemm_f16: conv_shift must be 0 or 1 (not with upsample)");
     } else if (a->mode == EW_A_CONVT3) {
         taps = 3;
         EW_REQUIRE(a->tB > 0 && a->tT > 0 && a->tP > 0 && (long long)a->tB * a->tT * a->tP == a->M,
@@ -321,7 +325,7 @@ extern "C" ew_status ew_gemm_f16(const ew_gemm_args* a, void* stream) {
     } else {
         EW_REQUIRE(a->mode == EW_A_DENSE, "ew_gemm_f16: unknown mode %d", a->mode);
     }
-    EW_REQUIRE(a->act == EW_ACT_NONE || a->act == EW_ACT_SILU || a->act == EW_ACT_GEGLU, "ew_gemm_f16: unknown act %d", a->act);
+    EW_REQUIRE(a->act == EW_ACT_NONE || a->act == EW_ACT_SILU || a->act == EW_ACT_GEGLU || a->act == EW_ACT_GELU, "ew_gemm_f16: unknown act %d", a->act);
     EW_REQUIRE(!a->rowbias || a->ld_rowbias % 4 == 0, "ew_gemm_f16: ld_rowbias must be a multiple of 4");
     if (a->act == EW_ACT_GEGLU)
         EW_REQUIRE(a->N % 128 == 0 && !a->rowbias && !a->r1 && !a->r2 && !a->out_lo, "ew_gemm_f16: GEGLU needs N %% 128 == 0 and no residuals");
@@ -331,6 +335,7 @@ extern "C" ew_status ew_gemm_f16(const ew_gemm_args* a, void* stream) {
     p.rowbias = (const f16*)a->rowbias; p.r1 = (const f16*)a->r1; p.r2 = (const f16*)a->r2; p.out = (f16*)a->out;
     p.zero_page = (const f16*)a->zero_page;
     p.r1_lo = (const f16*)a->r1_lo; p.r2_lo = (const f16*)a->r2_lo; p.out_lo = (f16*)a->out_lo;
+    p.conv_shift = a->conv_shift;
     p.M = a->M; p.N = a->N; p.K = taps * (a->c1 + a->c2);
     p.c1 = a->c1; p.c2 = a->c2; p.lda = a->lda; p.lda2 = a->lda2; p.ld_out = a->ld_out; p.ld_r1 = a->ld_r1; p.ld_r2 = a->ld_r2; p.ld_rowbias = a->ld_rowbias;
     p.mode = a->mode; p.n_img = a->n_img; p.h_in = a->h_in; p.w_in = a->w_in; p.h_out = a->h_out; p.w_out = a->w_out;

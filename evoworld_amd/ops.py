@@ -8,7 +8,7 @@ from . import _lib
 from ._lib import GemmArgs
 
 A_DENSE, A_CONV3X3, A_CONVT3 = 0, 1, 2
-ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_GELU = 0, 1, 2, 3
 
 _zero_pages = {}
 
@@ -67,9 +67,9 @@ def _hl(x):
 
 def gemm(a, w, out, *, M, N, c1, lda, a2=None, c2=0, lda2=0, bias=None, rowbias=None, rows_per_group=1, ld_rowbias=None,
          r1=None, ld_r1=0, r2=None, ld_r2=0, ld_out=None, mode=A_DENSE, conv=None, tconv=None, act=ACT_NONE,
-         c_acc=1.0, c_r1=1.0, c_r2=1.0):
+         c_acc=1.0, c_r1=1.0, c_r2=1.0, conv_shift=0):
     """out = c_acc*act(A@W^T + bias + rowbias) + c_r1*r1 + c_r2*r2  (see ew_gemm_f16).
-    conv = (n_img, h_in, w_in, h_out, w_out, stride, upsample); tconv = (B, T, P).
+    conv = (n_img, h_in, w_in, h_out, w_out, stride, upsample); tconv = (B, T, P); conv_shift=1: padding (0,1) taps.
     r1 / r2 / out may be `Res` (split-fp16 residual stream): the lo halves ride along (ew_gemm_args.r1_lo ...)."""
     lib = _lib.load()
     g = GemmArgs()
@@ -90,6 +90,7 @@ def gemm(a, w, out, *, M, N, c1, lda, a2=None, c2=0, lda2=0, bias=None, rowbias=
         g.tB, g.tT, g.tP = tconv
     g.rows_per_group, g.act = rows_per_group, act
     g.c_acc, g.c_r1, g.c_r2 = c_acc, c_r1, c_r2
+    g.conv_shift = conv_shift
     _lib.check(lib.ew_gemm_f16(ctypes.byref(g), _stream()), "ew_gemm_f16")
     return out
 
@@ -181,6 +182,27 @@ def attn_temporal(q, k, v, o, B, T, S, heads, ld, ld_o, scale=0.125):
     _lib.check(lib.ew_attn_temporal_f16(_ptr(q), _ptr(k), _ptr(v), _ptr(o), B, T, S, heads, ld, ld_o, scale, _stream()),
                "ew_attn_temporal_f16")
     return o
+
+
+def softmax_rows(scores, out=None):
+    """scores: fp16 [R, C] tensor or `Res` (hi + lo) -> fp16 softmax over the last dim (fp32 math)."""
+    lib = _lib.load()
+    h, l = _hl(scores)
+    R, C = h.shape
+    if out is None:
+        out = torch.empty_like(h)
+    _lib.check(lib.ew_softmax_rows_f16(_ptr(h), _ptr(l), _ptr(out), R, C, C, _stream()), "ew_softmax_rows_f16")
+    return out
+
+
+def time_conv3(x, w, bias):
+    """x fp32 [B,T,C,H,W], w fp32 [C,C,3], bias fp32 [C] -> fp32 [B,T,C,H,W] (Conv3d (3,1,1), zero padding in T)."""
+    lib = _lib.load()
+    _req(x, torch.float32, "x"); _req(w, torch.float32, "w"); _req(bias, torch.float32, "bias")
+    B, T, C, H, W = x.shape
+    y = torch.empty_like(x)
+    _lib.check(lib.ew_time_conv3_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, T, C, H * W, _stream()), "ew_time_conv3_f32")
+    return y
 
 
 def nchw_f32_to_nhwc_f16(x, y, ldc, c_off=0, scale=1.0):
@@ -325,6 +347,44 @@ def f32_chw_to_u8_hwc(src):
     dst = torch.empty(V, H, W, 3, dtype=torch.uint8, device=src.device)
     _lib.check(lib.ew_f32_chw_to_u8_hwc(_ptr(src), _ptr(dst), V, H, W, _stream()), "ew_f32_chw_to_u8_hwc")
     return dst
+
+
+def blur_axis(x, kern, axis):
+    """x fp32 [..., H, W], kern fp32 [k] -> correlation along H (axis 0) or W (axis 1), reflect padding."""
+    lib = _lib.load()
+    _req(x, torch.float32, "x"); _req(kern, torch.float32, "kern")
+    H, W = x.shape[-2:]
+    out = torch.empty_like(x)
+    _lib.check(lib.ew_blur_axis_f32(_ptr(x), _ptr(kern), kern.numel(), _ptr(out), x.numel() // (H * W), H, W, axis, _stream()),
+               "ew_blur_axis_f32")
+    return out
+
+
+def bicubic_resize(x, Ho, Wo, scale=None, shift=None):
+    """x fp32 [N,C,H,W] -> [N,C,Ho,Wo], bicubic align_corners=True; optional per-channel out = v*scale[c] + shift[c]."""
+    lib = _lib.load()
+    _req(x, torch.float32, "x")
+    N, C, H, W = x.shape
+    out = torch.empty(N, C, Ho, Wo, dtype=torch.float32, device=x.device)
+    _lib.check(lib.ew_bicubic_resize_f32(_ptr(x), _ptr(out), N, C, H, W, Ho, Wo, _ptr(scale), _ptr(shift), _stream()),
+               "ew_bicubic_resize_f32")
+    return out
+
+
+def vit_patchify(x, P, ldk):
+    lib = _lib.load()
+    _req(x, torch.float32, "x")
+    N, _, S, _ = x.shape
+    out = torch.empty(N * (S // P) ** 2, ldk, dtype=torch.float16, device=x.device)
+    _lib.check(lib.ew_vit_patchify_f16(_ptr(x), _ptr(out), N, S, P, ldk, _stream()), "ew_vit_patchify_f16")
+    return out
+
+
+def attn_small(q, k, v, o, n_seq, S, heads, D, ld, ld_o, scale):
+    lib = _lib.load()
+    _lib.check(lib.ew_attn_small_f16(_ptr(q), _ptr(k), _ptr(v), _ptr(o), n_seq, S, heads, D, ld, ld_o, float(scale), _stream()),
+               "ew_attn_small_f16")
+    return o
 
 
 def pack_conv_weight(w, cpad=None):

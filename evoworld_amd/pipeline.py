@@ -49,11 +49,38 @@ class StableVideoDiffusionPipeline:
     @classmethod
     def from_pretrained(cls, path=None, unet=None, **kw):
         """The reference builds the pipeline from a diffusers folder and injects its own unet
-        (unified_loop_consistency.py:193-197).  VAE / CLIP loading is a 'next' row; pass them via kw if available."""
+        (unified_loop_consistency.py:193-197: StableVideoDiffusionPipeline.from_pretrained(svd_path, unet=unet, ...)).
+        The folder's `vae/` (AutoencoderKLTemporalDecoder), `image_encoder/` (CLIPVisionModelWithProjection) and
+        `feature_extractor/preprocessor_config.json` (image_mean / image_std) are loaded onto the HIP implementations when
+        present; components passed as keywords win."""
+        import json
+        import os
         if unet is None:
             raise ValueError("pass unet= (evoworld_amd.unet.UNetSpatioTemporalConditionModel)")
-        return cls(unet=unet, scheduler=kw.get("scheduler"), vae=kw.get("vae"), image_encoder=kw.get("image_encoder"),
-                   feature_extractor=kw.get("feature_extractor"))
+        dev = unet.device or "cuda"
+        vae, enc, fe = kw.get("vae"), kw.get("image_encoder"), kw.get("feature_extractor")
+        if path and os.path.isdir(path):
+            if vae is None and os.path.isdir(os.path.join(path, "vae")):
+                from .vae import AutoencoderKLTemporalDecoder
+                vae = AutoencoderKLTemporalDecoder.from_pretrained(path, subfolder="vae", device=dev)
+            if enc is None and os.path.isdir(os.path.join(path, "image_encoder")):
+                from .clip import CLIPVisionModelWithProjection
+                enc = CLIPVisionModelWithProjection.from_pretrained(path, subfolder="image_encoder", device=dev)
+            pj = os.path.join(path, "feature_extractor", "preprocessor_config.json")
+            if fe is None and os.path.exists(pj):
+                raw = json.load(open(pj))
+                fe = SimpleNamespace(image_mean=raw.get("image_mean"), image_std=raw.get("image_std"))
+        return cls(unet=unet, scheduler=kw.get("scheduler"), vae=vae, image_encoder=enc, feature_extractor=fe)
+
+    def _encode_image(self, image01):
+        """pipeline_evoworld.py:255-305: [0,1] image -> x*2-1 -> antialiased resize to 224x224 -> (x+1)/2 -> CLIP mean / std
+        normalisation (feature_extractor with do_resize / do_center_crop / do_rescale off) -> image_encoder -> [N,1,X]."""
+        from .clip import CLIP_MEAN, CLIP_STD, encode_image_preprocess
+        fe = self.feature_extractor
+        mean = tuple(getattr(fe, "image_mean", None) or CLIP_MEAN)
+        std = tuple(getattr(fe, "image_std", None) or CLIP_STD)
+        pixel_values = encode_image_preprocess(image01.to(self._device), mean, std)
+        return self.image_encoder(pixel_values).image_embeds.unsqueeze(1)
 
     def to(self, device=None, dtype=None):
         return self
@@ -167,7 +194,7 @@ class StableVideoDiffusionPipeline:
                                  "(VAE and CLIP are 'next' rows, SURVEY.md §8f N1/N2)")
             img = torch.cat([image.unsqueeze(1), memorized_pixel_values], dim=1).to(dev)   # :570
             img = img / 2.0 + 0.5                                                           # :579
-            image_embeddings = self.image_encoder(img[:, 0]).image_embeds.unsqueeze(1)
+            image_embeddings = self._encode_image(img[:, 0])
             flat = img.flatten(0, 1) * 2.0 - 1.0                                            # VideoProcessor.preprocess
             noise = image_noise if image_noise is not None else torch.randn(
                 flat.shape, generator=generator, device=(generator.device if isinstance(generator, torch.Generator) else dev),

@@ -37,7 +37,7 @@ const char* ew_last_error(void);
  *                                                         is ordered [channel chunk of 64][tap][64 channels] (chunk-major,
  *                                                         tap-minor: the taps of a chunk re-hit its input lines in L2)
  *   v   = acc + bias[n] + rowbias[(m / rows_per_group) * ld_rowbias + n]
- *   v   = act(v)            act 0: none; 1: SiLU; 2: GEGLU -> out has N/2 columns (see w layout note below)
+ *   v   = act(v)            act 0: none; 1: SiLU; 2: GEGLU -> out has N/2 columns (see w layout note below); 3: erf GELU
  *   out = c_acc*v + c_r1*r1[m][n] + c_r2*r2[m][n]
  * A-operand addressing modes (the gather happens in the global->LDS DMA address, no im2col buffer):
  *   EW_A_DENSE   A(m, k)          = a[m*lda + k]                      (k < c1; then a2[m*lda2 + k-c1])
@@ -55,7 +55,7 @@ const char* ew_last_error(void);
  * 16q.., [32q+16,32q+32) = gate rows (N/2 + 16q..); bias likewise (evoworld_amd.unet packs this).
  */
 enum { EW_A_DENSE = 0, EW_A_CONV3X3 = 1, EW_A_CONVT3 = 2 };
-enum { EW_ACT_NONE = 0, EW_ACT_SILU = 1, EW_ACT_GEGLU = 2 };
+enum { EW_ACT_NONE = 0, EW_ACT_SILU = 1, EW_ACT_GEGLU = 2, EW_ACT_GELU = 3 /* erf GELU (CLIP ViT-H MLP) */ };
 
 typedef struct ew_gemm_args {
     const void* a;      /* fp16 */
@@ -84,6 +84,9 @@ typedef struct ew_gemm_args {
     const void* r1_lo;
     const void* r2_lo;
     void* out_lo;
+    /* EW_A_CONV3X3 tap origin: 0 = iy = oy*stride + ky - 1 (symmetric padding 1); 1 = iy = oy*stride + ky, zero beyond the
+     * bottom / right edge (F.pad(x, (0,1,0,1)) + stride-2 conv of diffusers Downsample2D(padding=0), the VAE encoder). */
+    int conv_shift;
 } ew_gemm_args;
 
 ew_status ew_gemm_f16(const ew_gemm_args* args, void* stream);
@@ -158,6 +161,33 @@ ew_status ew_nhwc_f16_to_nchw_f32(const void* x, float* y, int N, int C, int H, 
  * Replaces evoworld/pipeline/pipeline_evoworld.py:691-695,709-714 + EulerDiscreteScheduler.step/scale_model_input. */
 ew_status ew_euler_cfg_step(const void* eps, int ld_eps, float* latents, const float* guidance, float sigma,
                             float sigma_next, void* next_in, int cpad, int T, int h, int w, void* stream);
+
+/* Row softmax for the VAE's single-head attention (AutoencoderKLTemporalDecoder mid blocks, head_dim 512: diffusers
+ * Attention with upcast_softmax; pipeline_evoworld.py:307-328,358-385 via vae.encode / vae.decode): the [S,S] score matrix
+ * of one frame comes out of ew_gemm_f16 as split fp16 (hi + lo, so no fp16 rounding before the exponential);
+ * out[r][:] = softmax(hi[r][:] + lo[r][:]) in fp32, stored fp16.  lo may be NULL.  cols % 8 == 0. */
+ew_status ew_softmax_rows_f16(const void* hi, const void* lo, void* out, long long rows, int cols, long long ld, void* stream);
+
+/* TemporalDecoder.time_conv_out: Conv3d(C, C, (3,1,1), padding (1,0,0)) over fp32 frames x [B,T,C,HW] (C <= 4; w [C,C,3],
+ * bias [C]); zero padding along T.  Replaces the last op of diffusers TemporalDecoder.forward. */
+ew_status ew_time_conv3_f32(const float* x, const float* w, const float* bias, float* y, int B, int T, int C, int HW, void* stream);
+
+/* CLIP image-encoder path (pipeline_evoworld.py:255-305 `_encode_image`, :746-850
+ * `_resize_with_antialiasing`).  All fp32 planes [planes, H, W]:
+ *   ew_blur_axis_f32       1-D correlation along H (axis 0) or W (axis 1) with torch 'reflect' padding, pad_front = (ksize-1)/2
+ *                          (`_filter2d` with a [1,k] / [k,1] Gaussian)
+ *   ew_bicubic_resize_f32  F.interpolate(mode="bicubic", align_corners=True) (A = -0.75), optional per-channel affine
+ *                          out = v*scale[c] + shift[c] (folds (x+1)/2 and the CLIP mean / std normalisation)
+ *   ew_vit_patchify_f16    pixel_values [N,3,S,S] -> fp16 [N*(S/P)^2, ldk] im2col of the stride-P patch embedding, K order (c,ky,kx)
+ *   ew_attn_small_f16      softmax(q k^T * scale) v for short sequences (S <= 2048) and any head_dim % 8 == 0 (ViT-H: 257 x 80),
+ *                          one wave per query, fp32 math; q,k,v token-major rows with stride ld, head h at +h*D. */
+ew_status ew_blur_axis_f32(const float* x, const float* kern, int ksize, float* out, long long planes, int H, int W, int axis,
+                           void* stream);
+ew_status ew_bicubic_resize_f32(const float* x, float* out, int N, int C, int H, int W, int Ho, int Wo, const float* scale,
+                                const float* shift, void* stream);
+ew_status ew_vit_patchify_f16(const float* x, void* out, int N, int S, int P, int ldk, void* stream);
+ew_status ew_attn_small_f16(const void* q, const void* k, const void* v, void* o, int n_seq, int S, int heads, int D, int ld,
+                            int ld_o, float scale, void* stream);
 
 /* Plücker embedding: out[n, 0:3, y, x] = R_n d(y,x); out[n, 3:6] = t_n x (R_n d)  (fp32).
  * rays [H,W,3] fp32, c2w [N,3,4] fp32 -> out [N,6,H,W] fp32.

@@ -140,7 +140,12 @@ def test_full_call_surface_with_component_duck_types(models):
     # CPU restatement of the assembly with the same generator
     gen = torch.Generator().manual_seed(123)
     img = torch.cat([image.unsqueeze(1), memory], dim=1) / 2.0 + 0.5
-    ehs = clip(img[:, 0]).image_embeds.unsqueeze(1)
+    # _encode_image (pipeline_evoworld.py:264-285): x*2-1 -> antialiased resize to 224 -> (x+1)/2 -> CLIP mean / std
+    from evoworld_amd.clip import CLIP_MEAN, CLIP_STD
+    from oracle.clip_ref import resize_with_antialiasing_ref
+    pv = (resize_with_antialiasing_ref(img[:, 0] * 2.0 - 1.0, (224, 224)) + 1.0) / 2.0
+    pv = (pv - torch.tensor(CLIP_MEAN)[None, :, None, None]) / torch.tensor(CLIP_STD)[None, :, None, None]
+    ehs = clip(pv).image_embeds.unsqueeze(1)
     flat = img.flatten(0, 1) * 2.0 - 1.0
     flat = flat + 0.02 * torch.randn(flat.shape, generator=gen)
     il = vae.encode(flat).latent_dist.mode().reshape(1, T + 1, 4, H // 8, W // 8)
