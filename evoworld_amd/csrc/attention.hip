@@ -340,6 +340,126 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
     }
 }
 
+// Temporal attention for 32 < T <= 64 frames (BASELINE.json configs[4]: T = 49): same coalesced staging and MFMA layout as
+// attn_temporal_kernel, with two 32-row blocks on the query and on the key axis.  One wave per (batch, pixel, head); q, k
+// and v rows live in three wave-private LDS regions of 64 rows x 144 B (rows >= T zero-filled); the o rows of a query block
+// overwrite its q rows.
+__global__ __launch_bounds__(256) void attn_temporal64_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+                                                              const f16* __restrict__ v, f16* __restrict__ o, int B, int T,
+                                                              int S, int heads, int ld, int ld_o, float scale_log2e,
+                                                              long long n_prob) {
+    extern __shared__ __attribute__((aligned(16))) char smem_t64[];       // 4 waves x 3 regions x 64 x 144
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lh = lane >> 5, lr = lane & 31;
+    const long long pid = (long long)blockIdx.x * 4 + wave;
+    const bool active = pid < n_prob;
+    const long long pc = active ? pid : n_prob - 1;
+    const int h = (int)(pc % heads);
+    const long long bs = pc / heads;
+    const int b = (int)(bs / S), s = (int)(bs - (long long)b * S);
+    char* const rq = smem_t64 + wave * (3 * 64 * 144);
+    char* const rk = rq + 64 * 144;
+    char* const rv = rk + 64 * 144;
+    const long long row0 = (long long)b * T * S + s;
+    const int n_chunk = T * 8;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = it * 64 + lane;                                     // (row idx>>3, 16-byte column idx&7), rows 0..63
+        f16x8 a = {}, bb = {}, c = {};
+        if (idx < n_chunk) {
+            const long long off = (row0 + (long long)(idx >> 3) * S) * ld + h * 64 + (idx & 7) * 8;
+            a = *(const f16x8*)(q + off);
+            bb = *(const f16x8*)(k + off);
+            c = *(const f16x8*)(v + off);
+        }
+        const int lo = (idx >> 3) * 144 + (idx & 7) * 16;
+        *(f16x8*)(rq + lo) = a;
+        *(f16x8*)(rk + lo) = bb;
+        *(f16x8*)(rv + lo) = c;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    const int nqb = T > 32 ? 2 : 1;
+    for (int qb = 0; qb < nqb; ++qb) {
+        f16x8 qf[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) qf[st] = *(const f16x8*)(rq + (qb * 32 + lr) * 144 + st * 32 + lh * 16);
+        f32x16 sacc[2];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const f16x8 kf = *(const f16x8*)(rk + (kb * 32 + lr) * 144 + st * 32 + lh * 16);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], sacc[kb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (key >= T) sacc[kb][r] = -INFINITY;
+                mx = fmaxf(mx, sacc[kb][r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float nm = -mx * scale_log2e;
+        float l = 0.f;
+        f16x8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const f16 ph = (f16)__builtin_amdgcn_exp2f(fmaf(sacc[kb][g2 * 8 + e], scale_log2e, nm));
+                    l += (float)ph;
+                    pf[kb][g2][e] = ph;
+                }
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        f32x16 oacc[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    f16x8 vf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int key = kb * 32 + 16 * g2 + 4 * lh + (e & 3) + 8 * (e >> 2);
+                        vf[e] = *(const f16*)(rv + key * 144 + (db * 32 + lr) * 2);
+                    }
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][g2], oacc[db], 0, 0, 0);
+                }
+        }
+        // all lanes hold their q fragments in registers: the q rows of this block become its o rows
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f16x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = (f16)(oacc[db][r4 * 4 + e] * inv);
+                *(f16x4*)(rq + (qb * 32 + lr) * 144 + (32 * db + 8 * r4 + 4 * lh) * 2) = ov;
+            }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = it * 64 + lane;
+        if (idx < n_chunk && active)
+            *(f16x8*)(o + (row0 + (long long)(idx >> 3) * S) * ld_o + h * 64 + (idx & 7) * 8) =
+                *(const f16x8*)(rq + (idx >> 3) * 144 + (idx & 7) * 16);
+    }
+}
+
 }  // namespace
 
 extern "C" ew_status ew_attn_spatial_f16(const void* q, const void* k, const void* vt, void* o, int n_seq, int S, int heads,
@@ -360,11 +480,23 @@ extern "C" ew_status ew_attn_spatial_f16(const void* q, const void* k, const voi
 extern "C" ew_status ew_attn_temporal_f16(const void* q, const void* k, const void* v, void* o, int B, int T, int S,
                                           int heads, int ld, int ld_o, float scale, void* stream) {
     EW_REQUIRE(q && k && v && o, "ew_attn_temporal_f16: null pointer");
-    EW_REQUIRE(B > 0 && S > 0 && heads > 0 && T > 0 && T <= 32, "ew_attn_temporal_f16: need 0 < T <= 32 (T=%d)", T);
+    EW_REQUIRE(B > 0 && S > 0 && heads > 0 && T > 0 && T <= 64, "ew_attn_temporal_f16: need 0 < T <= 64 (T=%d)", T);
     EW_REQUIRE(ld % 8 == 0 && ld_o % 8 == 0, "ew_attn_temporal_f16: strides must be 16-byte aligned");
     const long long n_prob = (long long)B * S * heads;
     const long long nblk = (n_prob + 3) / 4;
     EW_REQUIRE(nblk < 0x7fffffffLL, "ew_attn_temporal_f16: grid too large");
+    if (T > 32) {
+        const size_t lds = 4 * 3 * 64 * 144;                        // 110,592 B
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn_temporal64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { ew_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return EW_ERR_HIP; }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(attn_temporal64_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, (const f16*)q,
+                           (const f16*)k, (const f16*)v, (f16*)o, B, T, S, heads, ld, ld_o, scale * 1.4426950408889634f, n_prob);
+        return ew_check_launch("ew_attn_temporal_f16");
+    }
     hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const f16*)q,
                        (const f16*)k, (const f16*)v, (f16*)o, B, T, S, heads, ld, ld_o, scale * 1.4426950408889634f, n_prob);
     return ew_check_launch("ew_attn_temporal_f16");

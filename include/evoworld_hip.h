@@ -140,7 +140,7 @@ ew_status ew_layernorm_f16(const void* x, const void* x_lo, const void* addvec, 
 ew_status ew_attn_spatial_f16(const void* q, const void* k, const void* vt, void* o, int n_seq, int S, int heads,
                               int ld_qk, long long ld_vt, int ld_o, float scale, void* stream);
 
-/* Temporal self-attention core over the frame axis (T <= 32, head_dim 64) on frame-major tokens
+/* Temporal self-attention core over the frame axis (T <= 64, head_dim 64; T <= 32 runs the one-block kernel) on frame-major tokens
  * [B, T, S, *]: sequence (b, s) attends over t -- the [B*T,S,C] <-> [B*S,T,C] regroup of
  * TemporalBasicTransformerBlock is done by addressing, not by a copy.  q,k,v row stride ld; o row stride ld_o.
  * Replaces SDPA in TemporalBasicTransformerBlock.attn1. */

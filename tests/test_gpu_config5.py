@@ -1,0 +1,63 @@
+"""-m gpu: BASELINE.json configs[4] enablement (1024x2048 panoramas -> 128x256 latents, T = 49 frames): the shapes that
+config needs beyond configs[1] -- temporal attention over 49 frames (two 32-key blocks), tensors beyond the 32-bit offset
+range of the generation-3 epilogue (served by generation 2's 64-bit addressing), S = 32768 spatial attention -- as a
+property test on a shrunken-width U-Net at the real latent size: batch independence of the CFG halves, finiteness, and
+agreement of two kernel families (default vs generation-1 GEMMs), since the fp32 oracle would take hours at this size."""
+import ctypes
+
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_unet_T49_at_128x256_latents_properties():
+    from evoworld_amd import _lib
+    from evoworld_amd.unet import UNetSpatioTemporalConditionModel
+    from oracle.unet_ref import tiny_config
+    cfg = tiny_config()
+    cfg["num_frames"] = 49
+    unet = UNetSpatioTemporalConditionModel.from_random(seed=0, device=DEV, **cfg)
+    B, T, h, w = 2, 49, 128, 256
+    g = torch.Generator().manual_seed(0)
+    x = torch.zeros(B * T * h * w, 64, dtype=torch.float16)
+    x[:, :18] = torch.randn(B * T * h * w, 18, generator=g).half()
+    ehs = torch.randn(B, 1, cfg["cross_attention_dim"], generator=g).half()
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * B)
+    x, ehs, ids = x.to(DEV), ehs.to(DEV), ids.to(DEV)
+    a = unet.forward_nhwc(x, 1.234, ehs, ids, B, T, h, w).float()
+    assert a.shape == (B * T * h * w, 4) and torch.isfinite(a).all() and float(a.abs().mean()) > 1e-4
+    rows = T * h * w
+    one = unet.forward_nhwc(x[rows:].contiguous(), 1.234, ehs[1:], ids[1:], 1, T, h, w).float()
+    e = rel_l2(one.cpu(), a[rows:].cpu())
+    print(f"config-5 shape: CFG-half independence rel-L2 {e:.2e}")
+    assert e < 2e-3        # B = 1 and B = 2 pick different tile shapes / kernel generations: fp16 rounding-order noise (measured 1.0e-3)
+    lib = _lib.load()
+    try:
+        lib.ew_set_gemm_generation(1)
+        b = unet.forward_nhwc(x, 1.234, ehs, ids, B, T, h, w).float()
+    finally:
+        lib.ew_set_gemm_generation(3)
+    e2 = rel_l2(a.cpu(), b.cpu())
+    print(f"config-5 shape: default vs generation-1 GEMMs rel-L2 {e2:.2e}")
+    assert e2 < 3e-3
+
+
+def test_pipeline_two_steps_T49():
+    """the pipeline call surface at T = 49 (guidance ramp, time-id, scheduler) on the tiny U-Net"""
+    from evoworld_amd.pipeline import StableVideoDiffusionPipeline
+    from evoworld_amd.unet import UNetSpatioTemporalConditionModel
+    from oracle.unet_ref import tiny_config
+    cfg = tiny_config()
+    cfg["num_frames"] = 49
+    unet = UNetSpatioTemporalConditionModel.from_random(seed=0, device=DEV, **cfg)
+    pipe = StableVideoDiffusionPipeline(unet=unet)
+    T, h, w = 49, 16, 32
+    g = torch.Generator().manual_seed(1)
+    out = pipe(torch.zeros(1, 3, h * 8, w * 8), height=h * 8, width=w * 8, num_frames=T, num_inference_steps=2,
+               latents=torch.randn(1, T, 4, h, w, generator=g), output_type="latent", plucker_embedding=torch.randn(1, T, 6, h, w, generator=g),
+               image_latents=torch.randn(1, T + 1, 4, h, w, generator=g), image_embeddings=torch.randn(1, 1, cfg["cross_attention_dim"], generator=g)).frames
+    assert out.shape == (1, T, 4, h, w) and torch.isfinite(out).all()

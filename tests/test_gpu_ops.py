@@ -266,7 +266,8 @@ def test_attn_spatial(ops, n_seq, S, heads):
     assert rel_l2(o.float().cpu(), ref.cpu()) < 2e-3
 
 
-@pytest.mark.parametrize("B,T,S,heads", [(2, 25, 37, 2), (1, 4, 512, 1), (2, 1, 9, 3), (1, 32, 5, 1)])
+@pytest.mark.parametrize("B,T,S,heads", [(2, 25, 37, 2), (1, 4, 512, 1), (2, 1, 9, 3), (1, 32, 5, 1), (2, 49, 21, 2), (1, 64, 7, 1),
+                                         (1, 33, 130, 3)])
 def test_attn_temporal(ops, B, T, S, heads):
     C = heads * 64
     rows = B * T * S
