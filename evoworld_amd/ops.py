@@ -130,7 +130,7 @@ class WorkspacePool:
 SumsPool = WorkspacePool   # former name
 
 
-def groupnorm(xs, gamma, beta, n_slabs, rows, eps, silu, groups=32, out=None, pool=None):
+def groupnorm(xs, gamma, beta, n_slabs, rows, eps, silu, groups=32, out=None, pool=None, stats_hi_only=False):
     """GroupNorm(+SiLU) over the channel concat of `xs` (list of [n_slabs*rows, C_i] fp16 tensors or `Res`) ->
     [n_slabs*rows, sum C_i] fp16.  Deterministic shifted statistics: stats per source, one finalize, apply per source."""
     lib = _lib.load()
@@ -144,8 +144,11 @@ def groupnorm(xs, gamma, beta, n_slabs, rows, eps, silu, groups=32, out=None, po
     st = _stream()
     off = 0
     for h, l in srcs:
-        _lib.check(lib.ew_groupnorm_stats_f16(_ptr(h), _ptr(l), _ptr(ws), n_slabs, rows, h.shape[-1], off, C_tot, groups, st),
-                   "ew_groupnorm_stats_f16")
+        # stats_hi_only (off): statistics from the hi half alone would save the lo read of this pass (2.3 ms per forward), but
+        # the rounding remainders add ulp^2/12 to the variance -- 0.5 % when a channel's std is ~4 fp16 ulps of its mean
+        # (mean/std = 300), i.e. exactly the cancellation-prone inputs the shifted statistics exist for
+        _lib.check(lib.ew_groupnorm_stats_f16(_ptr(h), None if stats_hi_only else _ptr(l), _ptr(ws), n_slabs, rows, h.shape[-1],
+                                              off, C_tot, groups, st), "ew_groupnorm_stats_f16")
         off += h.shape[-1]
     _lib.check(lib.ew_groupnorm_finalize(_ptr(ws), n_slabs, rows, C_tot, groups, st), "ew_groupnorm_finalize")
     off = 0

@@ -511,14 +511,17 @@ class UNetSpatioTemporalConditionModel:
         pos = self._pos_emb(t, B, T)
         nin = ops.layernorm(h, d["t_norm_ing"], d["t_norm_inb"], addvec=pos, rows_per_group=S)
         ffh = ops.linear(nin, d["t_fi1w"], d["t_fi1b"], act=ACT_GEGLU)
-        hm = ops.linear(ffh, d["t_fi2w"], d["t_fi2b"], out=self._res(rows, C, dev), r1=h, ld_r1=C, rowbias=pos,
+        # hm after ff_in and after the temporal attention are the two stream tensors whose fp16 rounding matters least
+        # (tests/analysis_fp16_floor.py per-tensor ablation: +0.036e-6 and +0.021e-6 of squared rel-L2 against 0.25e-6 for a
+        # resblock output): they are kept as plain fp16, which saves their lo halves' write + two reads
+        hm = ops.linear(ffh, d["t_fi2w"], d["t_fi2b"], out=Res.empty(rows, C, dev, False), r1=h, ld_r1=C, rowbias=pos,
                         rows_per_group=S, ld_rowbias=C)
         del ffh
         n1 = ops.layernorm(hm, d["t_norm1g"], d["t_norm1b"])
         qkv = ops.linear(n1, d["t_qkv"])
         ops.attn_temporal(qkv, qkv[:, C:], qkv[:, 2 * C:], ao, B, T, S, t.heads, 3 * C, C)
         del qkv
-        hm = ops.linear(ao, d["t_ow"], d["t_ob"], out=self._res(rows, C, dev), rowbias=cv_t, rows_per_group=T * S,
+        hm = ops.linear(ao, d["t_ow"], d["t_ob"], out=Res.empty(rows, C, dev, False), rowbias=cv_t, rows_per_group=T * S,
                         ld_rowbias=self._cv_total, r1=hm, ld_r1=C)
         n3 = ops.layernorm(hm, d["t_norm3g"], d["t_norm3b"])
         ffh = ops.linear(n3, d["t_f1w"], d["t_f1b"], act=ACT_GEGLU)

@@ -50,8 +50,14 @@ class TimestepEmbedding(nn.Module):
 RES_Q = None   # analysis knob (tests/analysis_fp16_floor.py): a function applied at every residual-stream tensor
 
 
-def _rq(x):
-    return x if RES_Q is None else RES_Q(x)
+def _rq(x, tag=""):
+    """residual-stream hook: RES_Q(x) or, when it accepts two arguments, RES_Q(x, tag)"""
+    if RES_Q is None:
+        return x
+    try:
+        return RES_Q(x, tag)
+    except TypeError:
+        return RES_Q(x)
 
 
 class ResnetBlock2D(nn.Module):
@@ -70,7 +76,7 @@ class ResnetBlock2D(nn.Module):
         h = self.conv2(F.silu(self.norm2(h)))
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
-        return _rq(x + h)
+        return _rq(x + h, "res_sp")
 
 
 class TemporalResnetBlock(nn.Module):
@@ -123,7 +129,7 @@ class SpatioTemporalResBlock(nn.Module):
         B = BF // T
         xs = x.reshape(B, T, C, H, W).permute(0, 2, 1, 3, 4)
         xt = self.temporal_res_block(xs, temb.reshape(B, T, -1))
-        y = _rq(self.time_mixer(xs, xt))
+        y = _rq(self.time_mixer(xs, xt), "res_out")
         return y.permute(0, 2, 1, 3, 4).reshape(BF, C, H, W)
 
 
@@ -184,8 +190,8 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, x, ctx, exec_dead=False):
         x = x + self.attn1(self.norm1(x))
-        x = _rq(x + self.attn2(self.norm2(x), ctx, exec_dead))   # product: one epilogue (attn1 out-proj + folded attn2)
-        x = _rq(x + self.ff(self.norm3(x)))
+        x = _rq(x + self.attn2(self.norm2(x), ctx, exec_dead), "s_attn")   # product: one epilogue (attn1 out-proj + folded attn2)
+        x = _rq(x + self.ff(self.norm3(x)), "s_ff")
         return x
 
 
@@ -205,9 +211,9 @@ class TemporalBasicTransformerBlock(nn.Module):
         BF, S, C = x.shape
         B = BF // T
         x = x.reshape(B, T, S, C).permute(0, 2, 1, 3).reshape(B * S, T, C)
-        x = _rq(x + self.ff_in(self.norm_in(x)))
+        x = _rq(x + self.ff_in(self.norm_in(x)), "t_ffin")
         x = x + self.attn1(self.norm1(x))
-        x = _rq(x + self.attn2(self.norm2(x), ctx, exec_dead))
+        x = _rq(x + self.attn2(self.norm2(x), ctx, exec_dead), "t_attn")
         x = x + self.ff(self.norm3(x))       # product: blended with the spatial branch in the same epilogue
         return x.reshape(B, S, T, C).permute(0, 2, 1, 3).reshape(BF, S, C)
 
@@ -234,15 +240,15 @@ class TransformerSpatioTemporalModel(nn.Module):
         time_ctx = first[:, None].expand(B, S, first.shape[-2], first.shape[-1]).reshape(B * S, -1, first.shape[-1])
         res = x
         h = self.norm(x).permute(0, 2, 3, 1).reshape(BF, S, C)
-        h = _rq(self.proj_in(h))
+        h = _rq(self.proj_in(h), "proj_in")
         frames = torch.arange(T, device=x.device).repeat(B)
         emb = self.time_pos_embed(timestep_embedding(frames, self.ch).to(h.dtype))[:, None, :]
         for blk, tblk in zip(self.transformer_blocks, self.temporal_transformer_blocks):
             h = blk(h, ehs, exec_dead)
-            hm = tblk(_rq(h + emb), T, time_ctx, exec_dead)
-            h = _rq(self.time_mixer(h, hm))
+            hm = tblk(h + emb, T, time_ctx, exec_dead)     # product: h + emb is formed in the ff_in epilogue, never stored
+            h = _rq(self.time_mixer(h, hm), "blend")
         h = self.proj_out(h)
-        return _rq(h.reshape(BF, H, W, C).permute(0, 3, 1, 2) + res)
+        return _rq(h.reshape(BF, H, W, C).permute(0, 3, 1, 2) + res, "t_out")
 
 
 class Downsample2D(nn.Module):

@@ -81,3 +81,35 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def per_tensor_ablation():
+    """Which residual-stream tensors need the split-fp16 (hi + lo) form?  Operands of every conv / linear are rounded to fp16
+    (the floor), then ONE class of stream tensor at a time is additionally rounded to fp16 (oracle.unet_ref._rq tags); the
+    added squared rel-L2 per class is what keeping that class in plain fp16 costs.  Result on the tiny config (x1e-6):
+    resblock spatial out 0.25, resblock out 0.23, transformer out 0.19, proj_in 0.08, spatial attn 0.08, spatial ff 0.07,
+    temporal ff_in 0.04, temporal attn 0.02 against a floor of 0.56 -> the last two are kept in plain fp16 by the product."""
+    import oracle.unet_ref as O
+    torch.manual_seed(0)
+    cfg = tiny_config()
+    model = UNetRef(**cfg).eval()
+    g = torch.Generator().manual_seed(1)
+    model.load_state_dict({k: v.half().float() for k, v in random_state_dict({**DEFAULT_CONFIG, **cfg}, 0).items()}, strict=True)
+    T, h, w = cfg["num_frames"], 16, 32
+    x = torch.randn(2, T, 18, h, w, generator=g)
+    ehs = torch.randn(2, 1, cfg["cross_attention_dim"], generator=g)
+    ehs[0] = 0
+    inputs = (x, torch.tensor(1.234), ehs, torch.tensor([[6.0, 127.0, 0.02]] * 2))
+    mm = (torch.nn.Conv2d, torch.nn.Conv3d, torch.nn.Linear)
+    ref = run(model, inputs)
+    base = rel(run(model, inputs, pre=r16, kinds_pre=mm), ref)
+    print(f"operands only: {base:.3e}")
+    for tag in ("res_sp", "res_out", "t_out", "proj_in", "s_attn", "s_ff", "t_ffin", "t_attn", "blend"):
+        O.RES_Q = lambda t, tg, tag=tag: r16(t) if tg == tag else t
+        e = rel(run(model, inputs, pre=r16, kinds_pre=mm), ref)
+        print(f"  + fp16 {tag:8s}: {e:.3e}   added squared rel-L2 {(e * e - base * base) * 1e6:.3f}e-6")
+    O.RES_Q = None
+
+
+if __name__ == "__main__" and "--per-tensor" in sys.argv:
+    per_tensor_ablation()

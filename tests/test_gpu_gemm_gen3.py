@@ -153,3 +153,4 @@ def test_conv_temporal(ops, lib):
     y = 0.3 * ref + r1.float()
     assert rel_l2(g3.float().cpu(), y.cpu()) < 1e-3
     assert rel_l2(g3.float().cpu(), g1.float().cpu()) < 1e-3
+
