@@ -22,7 +22,7 @@ SYMBOLS = [
     "ew_depth_unproject", "ew_select_workspace_bytes", "ew_select_kth_f32", "ew_filter_compact_workspace_bytes",
     "ew_filter_compact", "ew_splat_cubemap", "ew_splat_resolve", "ew_equi2pers", "ew_resize_aa_u8",
     "ew_u8_hwc_to_f32_chw", "ew_f32_chw_to_u8_hwc", "ew_blur_axis_f32", "ew_bicubic_resize_f32", "ew_vit_patchify_f16",
-    "ew_attn_small_f16",
+    "ew_attn_small_f16", "ew_quant_rows_fp8", "ew_gemm_fp8",
 ]
 
 
@@ -94,6 +94,8 @@ def load():
         "ew_bicubic_resize_f32": [P, P, I, I, I, I, I, I, P, P, P],
         "ew_vit_patchify_f16": [P, P, I, I, I, I, P],
         "ew_attn_small_f16": [P, P, P, P, I, I, I, I, I, I, F, P],
+        "ew_quant_rows_fp8": [P, P, P, I, I, P],
+        "ew_gemm_fp8": [P, P, P, P, P, I, I, I, LL, P],
     }
     lib.ew_groupnorm_workspace_floats.argtypes = [c_int, c_int, c_int, c_int]
     lib.ew_groupnorm_workspace_floats.restype = c_size_t

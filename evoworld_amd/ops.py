@@ -390,6 +390,29 @@ def attn_small(q, k, v, o, n_seq, S, heads, D, ld, ld_o, scale):
     return o
 
 
+def quant_rows_fp8(x):
+    """x fp16 [M,K] -> (q uint8 [M,K] holding OCP e4m3 bytes, scale fp32 [M]) with x ~= q * scale[:, None]."""
+    lib = _lib.load()
+    _req(x, torch.float16, "x")
+    M, K = x.shape
+    q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(M, dtype=torch.float32, device=x.device)
+    _lib.check(lib.ew_quant_rows_fp8(_ptr(x), _ptr(q), _ptr(sc), M, K, _stream()), "ew_quant_rows_fp8")
+    return q, sc
+
+
+def gemm_fp8(a, a_scale, w, w_scale, out=None):
+    """a uint8 [M,K] (e4m3), w uint8 [N,K] (e4m3), scales fp32 -> fp16 [M,N] = (a @ w^T) * a_scale[:,None] * w_scale[None]."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float16, device=a.device)
+    _lib.check(lib.ew_gemm_fp8(_ptr(a), _ptr(a_scale), _ptr(w), _ptr(w_scale), _ptr(out), M, N, K, out.stride(0), _stream()),
+               "ew_gemm_fp8")
+    return out
+
+
 def pack_conv_weight(w, cpad=None):
     """[O, I, *taps] (Conv2d 3x3 / Conv3d (3,1,1)) fp32 -> fp16 [O, K] in the K order ew_gemm_f16's conv modes read:
     [I/64 chunks][taps][64 channels].  `cpad` zero-pads the input channels first (conv_in: 18 -> 64)."""

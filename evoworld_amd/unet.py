@@ -208,7 +208,7 @@ def _sinusoid(x, dim):
 class UNetSpatioTemporalConditionModel:
     def __init__(self, **config):
         cfg = dict(DEFAULT_CONFIG)
-        cfg.update(config)
+        cfg.update({k: v for k, v in config.items() if k != "qkv_fp8"})
         self._cfg = cfg
         self.config = SimpleNamespace(**cfg)
         self.arch = _arch(cfg)
@@ -222,6 +222,9 @@ class UNetSpatioTemporalConditionModel:
         mode = os.environ.get("EW_RESIDUAL", "split")
         self.split_residual = mode != "fp16"
         self.split_heads = mode == "split"     # also split the stream tensors produced WITHOUT a residual operand
+        # BASELINE.json configs[4]: q / k / v projections on the fp8 (e4m3) MFMA path (per-token activation scales,
+        # per-output-channel weight scales); off by default -- it changes the numerics contract (tests/test_gpu_fp8.py)
+        self.qkv_fp8 = bool(config.get("qkv_fp8", os.environ.get("EW_QKV_FP8", "0") == "1"))
         self._pos_cache = {}
         for hd, c in zip(cfg["num_attention_heads"], cfg["block_out_channels"]):
             if c // hd != 64:
@@ -386,6 +389,10 @@ class UNetSpatioTemporalConditionModel:
                     d["s_qk"], d["s_v"] = h(torch.cat([q, k_])), h(v)
                 else:
                     d["t_qkv"] = h(torch.cat([q, k_, v]))
+                if self.qkv_fp8:
+                    for nm, wt in ((("s_qk8", torch.cat([q, k_])), ("s_v8", v)) if tag == "s" else (("t_qkv8", torch.cat([q, k_, v])),)):
+                        sc = (wt.abs().amax(dim=1).clamp_min(1e-12) / 448.0).contiguous()          # per-output-channel scale
+                        d[nm] = ((wt / sc[:, None]).to(torch.float8_e4m3fn).view(torch.uint8).contiguous(), sc)
                 d[f"{tag}_ow"], d[f"{tag}_ob"] = h(f32(b + ".attn1.to_out.0.weight")), h(f32(b + ".attn1.to_out.0.bias"))
                 # cross attention with ONE key/value token: out = to_out(to_v(ctx)) -> fold the two matrices
                 cv_w.append(f32(b + ".attn2.to_out.0.weight") @ f32(b + ".attn2.to_v.weight"))
@@ -492,9 +499,14 @@ class UNetSpatioTemporalConditionModel:
         h = ops.linear(hn, d["piw"], d["pib"], out=self._res(rows, C, dev, head=True))
         # --- spatial BasicTransformerBlock ---
         n1 = ops.layernorm(h, d["s_norm1g"], d["s_norm1b"])
-        qk = ops.linear(n1, d["s_qk"])
-        vt = torch.empty(C, rows, dtype=torch.float16, device=dev)
-        ops.gemm(d["s_v"], n1, vt, M=C, N=rows, c1=C, lda=C)          # V^T = W_v X^T (swapped operands)
+        if self.qkv_fp8:
+            n8, nsc = ops.quant_rows_fp8(n1)
+            qk = ops.gemm_fp8(n8, nsc, *d["s_qk8"])
+            vt = ops.gemm_fp8(d["s_v8"][0], d["s_v8"][1], n8, nsc)   # V^T = W_v X^T: operand roles swapped
+        else:
+            qk = ops.linear(n1, d["s_qk"])
+            vt = torch.empty(C, rows, dtype=torch.float16, device=dev)
+            ops.gemm(d["s_v"], n1, vt, M=C, N=rows, c1=C, lda=C)      # V^T = W_v X^T (swapped operands)
         ao = torch.empty(rows, C, dtype=torch.float16, device=dev)
         ops.attn_spatial(qk, qk[:, C:], vt, ao, N, S, t.heads, 2 * C, rows, C)
         del qk, vt
@@ -518,7 +530,7 @@ class UNetSpatioTemporalConditionModel:
                         rows_per_group=S, ld_rowbias=C)
         del ffh
         n1 = ops.layernorm(hm, d["t_norm1g"], d["t_norm1b"])
-        qkv = ops.linear(n1, d["t_qkv"])
+        qkv = ops.gemm_fp8(*ops.quant_rows_fp8(n1), *d["t_qkv8"]) if self.qkv_fp8 else ops.linear(n1, d["t_qkv"])
         ops.attn_temporal(qkv, qkv[:, C:], qkv[:, 2 * C:], ao, B, T, S, t.heads, 3 * C, C)
         del qkv
         hm = ops.linear(ao, d["t_ow"], d["t_ob"], out=Res.empty(rows, C, dev, False), rowbias=cv_t, rows_per_group=T * S,

@@ -189,6 +189,14 @@ ew_status ew_vit_patchify_f16(const float* x, void* out, int N, int S, int P, in
 ew_status ew_attn_small_f16(const void* q, const void* k, const void* v, void* o, int n_seq, int S, int heads, int D, int ld,
                             int ld_o, float scale, void* stream);
 
+/* Optional fp8 (OCP e4m3) projections for the attention q / k / v GEMMs (BASELINE.json configs[4]).  Off by default; stated
+ * tolerance in tests/test_gpu_fp8.py.  ew_quant_rows_fp8: x fp16 [rows,K] -> q fp8 [rows,K], scale[row] = amax(row)/448.
+ * ew_gemm_fp8: out[m][n] = (sum_k a[m][k]*w[n][k]) * a_scale[m] * w_scale[n] (fp32 accumulate on v_mfma_f32_16x16x32_fp8_fp8,
+ * fp16 out, row stride ld_out).  K % 64 == 0, N % 4 == 0.  Swapping the operand roles yields the transposed product (V^T). */
+ew_status ew_quant_rows_fp8(const void* x, void* q, float* scale, int rows, int K, void* stream);
+ew_status ew_gemm_fp8(const void* a, const float* a_scale, const void* w, const float* w_scale, void* out, int M, int N, int K,
+                      long long ld_out, void* stream);
+
 /* Plücker embedding: out[n, 0:3, y, x] = R_n d(y,x); out[n, 3:6] = t_n x (R_n d)  (fp32).
  * rays [H,W,3] fp32, c2w [N,3,4] fp32 -> out [N,6,H,W] fp32.
  * Replaces utils/plucker_embedding.py:221-255 (ray_c2w_to_plucker). */
