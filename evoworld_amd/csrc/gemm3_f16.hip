@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                     // operands of step s+1 are requested BEFORE the store of step s -- but after step s has consumed its own.
                     f16x8 bvv, rbv, q1v, q2v, q1l, q2l;
                     const int rpg = p.rows_per_group;
-                    const int g0 = m_w0 / rpg;
+                    const int g0 = min(m_w0, p.M - 1) / rpg;             // wave tiles past the last row must not index a group beyond the last
                     const int gbound = rpg >= WM ? (g0 + 1) * rpg : 0x7fffffff;
                     const int ncol0 = n_w0 + fks * 8;
                     auto fetch = [&](int i, int q) {

@@ -53,8 +53,45 @@ class SyntheticStages:
                 "extrinsic": np.linalg.inv(poses)[:, :3, :4].astype(np.float32), "intrinsic": K}
 
 
+class HipStages(SyntheticStages):
+    """VAE (row N1) and CLIP (row N2) on the HIP implementations (`evoworld_amd.vae`, `evoworld_amd.clip`); only the depth
+    network (VGGT-1B, row N4) stays the synthetic stand-in.  Weights: `svd_path/vae`, `svd_path/image_encoder` when those
+    diffusers folders exist, otherwise random-init of the full architectures (timing / plumbing runs)."""
+
+    def __init__(self, svd_path=None, device="cuda", seed=0, noise_aug_strength=0.02, **kw):
+        super().__init__(**kw)
+        import os
+        from .clip import CLIPVisionModelWithProjection
+        from .vae import AutoencoderKLTemporalDecoder
+        have = lambda sub: bool(svd_path) and os.path.isdir(os.path.join(svd_path, sub))
+        self.vae = (AutoencoderKLTemporalDecoder.from_pretrained(svd_path, subfolder="vae", device=device) if have("vae")
+                    else AutoencoderKLTemporalDecoder.from_random(seed=seed, device=device))
+        self.clip = (CLIPVisionModelWithProjection.from_pretrained(svd_path, subfolder="image_encoder", device=device)
+                     if have("image_encoder") else CLIPVisionModelWithProjection.from_random(seed=seed, device=device))
+        self.noise_aug_strength = noise_aug_strength
+        self.decode_chunk_size = 8
+
+    def image_latents_fn(self, first, memory):
+        """pipeline_evoworld.py:570-623: CLIP embedding of the first frame; VAE mode() of [first | memory] + 0.02 * noise"""
+        from .clip import encode_image_preprocess
+        x = torch.cat([first[None], memory], 0)                                         # [-1,1]
+        emb = self.clip(encode_image_preprocess(x[:1] / 2 + 0.5)).image_embeds[:, None]
+        noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(-1 & 0x7fffffff)).to(x.device)
+        lat = self.vae.encode(x + self.noise_aug_strength * noise).latent_dist.mode()
+        return dict(image_latents=lat[None], image_embeddings=emb)
+
+    def frames_from_latents(self, latents):
+        """pipeline_evoworld.py:358-385: decode in chunks of decode_chunk_size after dividing by the scaling factor"""
+        z = latents[0].float() / self.vae.config.scaling_factor
+        c = self.decode_chunk_size
+        return torch.cat([self.vae.decode(z[i:i + c], num_frames=min(c, z.shape[0] - i)).sample for i in range(0, z.shape[0], c)])
+
+
 def load_stages(spec, args, **kw):
-    """spec 'pkg.mod:factory' -> factory(args); None -> SyntheticStages."""
+    """spec 'pkg.mod:factory' -> factory(args); 'hip' -> HipStages (VAE + CLIP on the HIP kernels); None -> SyntheticStages."""
+    if spec == "hip":
+        return HipStages(svd_path=getattr(args, "svd_path", None), cross_attention_dim=kw.get("cross_attention_dim", 1024),
+                         camera_params=kw.get("camera_params"), depth_hw=(392, 518))
     if not spec:
         return SyntheticStages(**kw)
     import importlib
