@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EW_LIB_PATH") or os.path.join(_HERE, "libevoworld_hip.so")   # EW_LIB_PATH: ablation builds (tools/)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol declared in include/evoworld_hip.h
 SYMBOLS = [

@@ -203,11 +203,10 @@ class CLIPVisionModelWithProjection:
         dev = x.device
         patches = ops.linear(ops.vit_patchify(x, P, W["kp"]), W["patch"])                  # [N*G, D]
         # token assembly ([class | patches] + position embedding): 257 x 1280 values per image -- host-side glue in fp32,
-        # split into the hi + lo stream
+        # split into the (hi, lo8) stream
         tok = torch.cat([W["cls"].expand(N, 1, D), patches.float().reshape(N, G, D)], dim=1) + W["pos"][None]
         tok = tok.reshape(N * S, D)
-        hi = tok.half()
-        hs = Res(hi.contiguous(), (tok - hi.float()).half().contiguous())
+        hs = Res.from_float(tok)
         h0 = ops.layernorm(hs, *W["pre"], eps=cfg["layer_norm_eps"])
         hs = Res(h0, None)                                       # pre_layrnorm output starts the stream
         hd = D // H
@@ -222,7 +221,6 @@ class CLIPVisionModelWithProjection:
             hs = ops.linear(f1, *lw["fc2"], out=Res.empty(N * S, D, dev, True), r1=hs, ld_r1=D)
         last = hs.float().reshape(N, S, D)
         pooled_in = last[:, 0]                                    # class token
-        ph = pooled_in.half().contiguous()
-        pooled = ops.layernorm(Res(ph, (pooled_in - ph.float()).half().contiguous()), *W["post"], eps=cfg["layer_norm_eps"])
+        pooled = ops.layernorm(Res.from_float(pooled_in), *W["post"], eps=cfg["layer_norm_eps"])
         emb = ops.linear(pooled, W["proj"])[:, : cfg["projection_dim"]].float()
         return SimpleNamespace(image_embeds=emb, last_hidden_state=last)

@@ -63,6 +63,38 @@ __device__ __forceinline__ f32x2 ew_vgelu2(f32x2 v, f32x2 g) {
     return (v * 0.5f) * __builtin_elementwise_fma(ag, y, g);
 }
 
+// ---- split residual stream: value = (hi fp16, lo8 int8) ------------------------------------------------------------------
+// hi = fp16(x) (round to nearest even: the half a consumer can feed to an fp16 MFMA as it is); lo8 = the distance from hi to x
+// in steps of 32 fp32 ulps, counted on the fp32 BIT PATTERN: bits(x) ~= bits((float)hi) + 32 * lo8.  |bits(x) - bits(hi)| <=
+// 2^12 for any x that rounds to a normal hi (also across a binade boundary, where the integer order of IEEE patterns keeps
+// encode and decode consistent), so lo8 in [-128, 127] carries 8 more mantissa bits (~19 in all) in ONE byte per element:
+// 3 bytes per stream element instead of the 4 of a second fp16 plane, decode = cvt + bfe + shift-add (no more VALU work than
+// the two cvt + add of an fp16 pair).  Tiny values (fp16-subnormal hi) lose the extra bits -- irrelevant for rel-L2.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float ew_split_dec(f16 hi, int lo8) {
+    return __int_as_float(__float_as_int((float)hi) + (lo8 << 5));
+}
+__device__ __forceinline__ int ew_split_enc(float x, f16 hi) {
+    const int d = (__float_as_int(x) - __float_as_int((float)hi) + 16) >> 5;
+    return min(max(d, -128), 127);
+}
+__device__ __forceinline__ int ew_sbyte(unsigned w, int i) { return (int)__builtin_amdgcn_sbfe((int)w, 8 * i, 8); }
+__device__ __forceinline__ void ew_split_dec8(const f16x8 hi, const u32x2 lo, float (&out)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = ew_split_dec(hi[e], ew_sbyte(lo[e >> 2], e & 3));
+}
+__device__ __forceinline__ unsigned ew_pack4(int a, int b, int c, int d) {
+    return (unsigned)(a & 255) | ((unsigned)(b & 255) << 8) | ((unsigned)(c & 255) << 16) | ((unsigned)d << 24);
+}
+// x[8] fp32 -> hi (fp16 x 8) + lo8 (8 bytes)
+__device__ __forceinline__ void ew_split_enc8(const float (&x)[8], f16x8& hi, u32x2& lo) {
+    int s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { hi[e] = (f16)x[e]; s[e] = ew_split_enc(x[e], hi[e]); }
+    lo[0] = ew_pack4(s[0], s[1], s[2], s[3]);
+    lo[1] = ew_pack4(s[4], s[5], s[6], s[7]);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -63,28 +63,27 @@ __global__ void euler_cfg_kernel(const f16* __restrict__ eps, int ld_eps, float*
 
 inline int grid_for(long long n) { long long b = (n + 255) / 256; return (int)(b < 4096 ? (b > 0 ? b : 1) : 4096); }
 
-// Row softmax of a score matrix carried as split fp16 (hi + lo): p[r][c] = exp(s[r][c] - max_r) / sum_r, fp32 math, fp16 out.
+// Row softmax of a score matrix carried split (hi fp16 + lo8, common.h): p[r][c] = exp(s[r][c] - max_r) / sum_r, fp32 math, fp16 out.
 // One wave per row, the row streams through registers in chunks of 8 columns per lane (two passes over the row: max+sum
 // with the online rescale, then normalise; the second pass re-reads the row from L2).  Used by the VAE's single-head
 // 512-wide attention (S = 9216 keys per frame): scores come from ew_gemm_f16 with out_lo, so nothing is rounded to fp16
 // before the exponential (diffusers Attention upcast_softmax).
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* __restrict__ hi, const f16* __restrict__ lo,
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* __restrict__ hi, const int8_t* __restrict__ lo,
                                                            f16* __restrict__ out, long long rows, int cols, long long ld) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const f16* h = hi + row * ld;
-    const f16* l = lo ? lo + row * ld : nullptr;
+    const int8_t* l = lo ? lo + row * ld : nullptr;
     float m = -INFINITY, sum = 0.f;
     for (int c = lane * 8; c < cols; c += 512) {
         const f16x8 a = *(const f16x8*)(h + c);
         float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
         if (l) {
-            const f16x8 b = *(const f16x8*)(l + c);
+            ew_split_dec8(a, *(const u32x2*)(l + c), v);
+        } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)b[e];
+            for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
         }
         float cm = v[0];
 #pragma unroll
@@ -103,12 +102,11 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* __restrict
     for (int c = lane * 8; c < cols; c += 512) {
         const f16x8 a = *(const f16x8*)(h + c);
         float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
         if (l) {
-            const f16x8 b = *(const f16x8*)(l + c);
+            ew_split_dec8(a, *(const u32x2*)(l + c), v);
+        } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)b[e];
+            for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
         }
         f16x8 r;
 #pragma unroll
@@ -182,7 +180,7 @@ extern "C" ew_status ew_softmax_rows_f16(const void* hi, const void* lo, void* o
     EW_REQUIRE(cols % 8 == 0 && ld % 8 == 0 && ld >= cols, "ew_softmax_rows_f16: cols and ld must be multiples of 8");
     EW_REQUIRE((rows + 3) / 4 < 0x7fffffffLL, "ew_softmax_rows_f16: too many rows");
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const f16*)hi,
-                       (const f16*)lo, (f16*)out, rows, cols, ld);
+                       (const int8_t*)lo, (f16*)out, rows, cols, ld);
     return ew_check_launch("ew_softmax_rows_f16");
 }
 

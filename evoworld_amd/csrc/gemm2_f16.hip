@@ -399,8 +399,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
                 // the epilogue serialised into ~12 store round trips per tile (measured: epilogue = main loop at K=320).
                 if constexpr ((EPI & 8) == 0) {
                     constexpr bool RB = EPI & 1, R1 = EPI & 2, R2 = EPI & 4, LO = EPI & 16;
-                    const f16* r1lp = p.r1_lo ? p.r1_lo : p.zero_page;      // split-fp16 residual stream companions
-                    const f16* r2lp = p.r2_lo ? p.r2_lo : p.zero_page;
+                    const int8_t* r1lp = p.r1_lo ? p.r1_lo : (const int8_t*)p.zero_page;      // split residual stream: lo8 companions
+                    const int8_t* r2lp = p.r2_lo ? p.r2_lo : (const int8_t*)p.zero_page;
                     const int m1l = p.r1_lo ? 1 : 0, m2l = p.r2_lo ? 1 : 0;
                     const int ld1l = p.r1_lo ? p.ld_r1 : 0, ld2l = p.r2_lo ? p.ld_r2 : 0;
                     constexpr int VPR = WN / 8;                 // 16-byte output vectors per row
@@ -417,15 +417,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
                         const int n = n_w0 + c8v[it];
                         bvv[it] = *(const f16x8*)(bp + ((FULL || n + 8 <= p.N) ? n : 0) * mbias);
                     }
-                    f16x8 rbv[2], q1v[2], q2v[2], q1l[2], q2l[2];
+                    f16x8 rbv[2], q1v[2], q2v[2];
+                    u32x2 q1l[2], q2l[2];
                     auto fetch = [&](int i, int it, int set) {
                         const int m = m_w0 + i * 16 + rowv[it], n = n_w0 + c8v[it];
                         const int mc = FULL ? m : min(m, p.M - 1), nc = (FULL || n + 8 <= p.N) ? n : 0;
                         if constexpr (RB) rbv[set] = *(const f16x8*)(rbp + (size_t)(mc / p.rows_per_group) * ldrb + nc * mrb);
                         if constexpr (R1) q1v[set] = *(const f16x8*)(r1p + (size_t)mc * ld1 + nc * m1);
                         if constexpr (R2) q2v[set] = *(const f16x8*)(r2p + (size_t)mc * ld2 + nc * m2);
-                        if constexpr (R1 && LO) q1l[set] = *(const f16x8*)(r1lp + (size_t)mc * ld1l + nc * m1l);
-                        if constexpr (R2 && LO) q2l[set] = *(const f16x8*)(r2lp + (size_t)mc * ld2l + nc * m2l);
+                        if constexpr (R1 && LO) q1l[set] = *(const u32x2*)(r1lp + (size_t)mc * ld1l + nc * m1l);
+                        if constexpr (R2 && LO) q2l[set] = *(const u32x2*)(r2lp + (size_t)mc * ld2l + nc * m2l);
                     };
                     fetch(0, 0, 0);
 #pragma unroll
@@ -446,7 +447,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
                             const f32x4 lo = *(const f32x4*)(patch + row * LDP + c8);
                             const f32x4 hi = *(const f32x4*)(patch + row * LDP + c8 + 4);
                             const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                            f16x8 o, ol;
+                            f16x8 o;
+                            int s8[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
                                 float x = v[e] + (float)bvv[it][e];
@@ -454,17 +456,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
                                 if (p.act == EW_ACT_SILU) x = ew_silu(x);
                                 else if (p.act == EW_ACT_GELU) x = ew_gelu(x);
                                 x *= p.c_acc;
-                                if constexpr (R1 && LO) x += p.c_r1 * ((float)q1v[set][e] + (float)q1l[set][e]);
+                                if constexpr (R1 && LO) x += p.c_r1 * ew_split_dec(q1v[set][e], ew_sbyte(q1l[set][e >> 2], e & 3));
                                 else if constexpr (R1) x += p.c_r1 * (float)q1v[set][e];
-                                if constexpr (R2 && LO) x += p.c_r2 * ((float)q2v[set][e] + (float)q2l[set][e]);
+                                if constexpr (R2 && LO) x += p.c_r2 * ew_split_dec(q2v[set][e], ew_sbyte(q2l[set][e >> 2], e & 3));
                                 else if constexpr (R2) x += p.c_r2 * (float)q2v[set][e];
                                 o[e] = (f16)x;
-                                if constexpr (LO) ol[e] = (f16)(x - (float)o[e]);
+                                if constexpr (LO) s8[e] = ew_split_enc(x, o[e]);
                             }
                             if (FULL ? is_live(it) : (is_live(it) && m < p.M && n + 8 <= p.N && !(p.dbg & 1))) {
                                 *(f16x8*)(p.out + (size_t)m * p.ld_out + n) = o;
                                 if constexpr (LO) {
-                                    if (p.out_lo) *(f16x8*)(p.out_lo + (size_t)m * p.ld_out + n) = ol;
+                                    if (p.out_lo)
+                                        *(u32x2*)(p.out_lo + (size_t)m * p.ld_out + n) =
+                                            (u32x2){ew_pack4(s8[0], s8[1], s8[2], s8[3]), ew_pack4(s8[4], s8[5], s8[6], s8[7])};
                                 }
                             } else if (!FULL && is_live(it) && m < p.M && !(p.dbg & 1)) {
 #pragma unroll
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
                                     if (n + e < p.N) {
                                         p.out[(size_t)m * p.ld_out + n + e] = o[e];
                                         if constexpr (LO) {
-                                            if (p.out_lo) p.out_lo[(size_t)m * p.ld_out + n + e] = ol[e];
+                                            if (p.out_lo) p.out_lo[(size_t)m * p.ld_out + n + e] = (int8_t)s8[e];
                                         }
                                     }
                             }

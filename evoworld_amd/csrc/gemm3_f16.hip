@@ -68,6 +68,9 @@ __device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, in
 template <int MODE, int EPI>
 __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // epilogue family: GEGLU (EPI & 8) and the conv modes without lo8 operands go through a wave-private LDS patch; dense GEMMs
+    // and everything that carries the split residual stream use the LDS-free direct epilogue (permuted W staging)
+    constexpr bool DIRECT = (EPI & 8) == 0 && (MODE == EW_A_DENSE || (EPI & 16));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
         // lane are 8 CONSECUTIVE output columns: fragment jj, row i = 4*fks + e  <-  column (jj>>1)*32 + fks*8 + (jj&1)*4 + e.
         // With u = wave + 8j that is column 64*j + f(wave, srow): the same 64-row stride per piece as the identity map.
         int wrow = wave * 8 + srow_o;
-        if constexpr ((EPI & 8) == 0)
+        if constexpr (DIRECT)
             wrow = (wave >> 2) * 32 + ((wave >> 1) & 1) * 4 + (2 * (wave & 1) + (srow_o >> 2)) * 8 + (srow_o & 3);
         b_ptr0 = p.w + (size_t)(n0 + wrow) * p.K + slot_o * 8;                        // N % 320 == 0: every W row exists
         ld_kt = 0; ld_tap = 0; ld_cc = 0;
@@ -315,20 +318,150 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                 constexpr int VPR = CP / 8;                 // 16-byte output vectors per row and pass
                 constexpr int ITERS = (16 * VPR + 63) / 64;  // 3 (the last one partial: 160 = 2*64 + 32)
                 auto is_live = [&](int it) { return it * 64 + lane < 16 * VPR; };
-                if constexpr ((EPI & 8) == 0) {
+                if constexpr (!DIRECT && (EPI & ~1) == 0) {
+                    // No residual operands: bias / row-bias / SiLU / scale are applied in the ACCUMULATOR layout (4 consecutive
+                    // columns per lane: 8-byte operand loads of L2-resident vectors) and the result goes through the patch as
+                    // fp16 -- half the LDS bytes of the fp32 patch, no conversion after the read-back.  Same values, rounded
+                    // once, as the general path below.
+                    constexpr bool RB = EPI & 1;
+                    constexpr int NH = WN / CP;
+                    constexpr int LDH = CP + 8;              // patch row stride in halfs (176 B)
+                    f16* patch16 = (f16*)patch;
+                    const int rpg = p.rows_per_group;
+                    const bool silu = p.act == EW_ACT_SILU, gelu = MODE == EW_A_DENSE && EPI == 0 && p.act == EW_ACT_GELU;
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+                        const int m_l = min(m_w0 + i * 16 + frow, p.M - 1);
+                        const int g = RB ? m_l / rpg : 0;
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) {
+#pragma unroll
+                            for (int jj = 0; jj < CP / 16; ++jj) {
+                                const int j = h * (CP / 16) + jj;
+                                const int n = n_w0 + j * 16 + fks * 4;
+                                const f16x4 b4 = *(const f16x4*)((const char*)bp + (unsigned)(n * mbias) * 2u);
+                                f32x4 x = acc[i][j] + (f32x4){(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
+                                if constexpr (RB) {
+                                    const f16x4 r4 = *(const f16x4*)((const char*)rbp + (unsigned)(g * ldrb + n * mrb) * 2u);
+                                    x += (f32x4){(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
+                                }
+                                if (silu) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) x[e] = ew_silu(x[e]);
+                                } else if (gelu) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) x[e] = ew_gelu(x[e]);
+                                }
+                                x *= p.c_acc;
+                                const f16x4 o4 = {(f16)x[0], (f16)x[1], (f16)x[2], (f16)x[3]};
+                                *(f16x4*)(patch16 + frow * LDH + jj * 16 + fks * 4) = o4;
+                                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            }
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int it = 0; it < ITERS; ++it) {
+                                const int idx = it * 64 + lane;
+                                const int row = is_live(it) ? idx / VPR : 0, c8 = is_live(it) ? (idx - row * VPR) * 8 : 0;
+                                const int m = m_w0 + i * 16 + row, n = n_w0 + h * CP + c8;
+                                const f16x8 o = *(const f16x8*)(patch16 + row * LDH + c8);
+                                if (is_live(it) && (FULL || m < p.M) && !(p.dbg & 1)) *(f16x8*)((char*)p.out + (unsigned)(m * p.ld_out + n) * 2u) = o;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                } else if constexpr (!DIRECT && (EPI & 8) == 0) {
+                    // general LDS-patch epilogue (conv modes without lo8 operands: the direct epilogue below costs them 11-18 spilled
+                    // VGPRs, some reloaded inside the K loop -- measured 4-10 % slower than this path)
+                    constexpr bool RB = EPI & 1, R1 = EPI & 2, R2 = EPI & 4;
+                    constexpr int NH = WN / CP;              // 2 column passes
+                    int rowv[ITERS], c8v[ITERS];
+#pragma unroll
+                    for (int it = 0; it < ITERS; ++it) {
+                        const int idx = it * 64 + lane;
+                        rowv[it] = is_live(it) ? idx / VPR : 0;
+                        c8v[it] = is_live(it) ? (idx - rowv[it] * VPR) * 8 : 0;
+                    }
+                    // vmcnt is in-order: a load issued after a store cannot be waited for without draining that store, so the
+                    // operands of store step s+1 are requested BEFORE the store of step s -- but AFTER step s has consumed
+                    // its own operands, into the same registers (one operand set: the 160 live accumulators leave no room
+                    // for two).
+                    f16x8 bvv, rbv, q1v, q2v;
+                    // row-bias group of a row: one boundary at most inside the wave's 64 rows when rows_per_group >= 64
+                    const int rpg = p.rows_per_group;
+                    const int g0 = min(m_w0, p.M - 1) / rpg;             // wave tiles past the last row must not index a group beyond the last
+                    const int gbound = rpg >= WM ? (g0 + 1) * rpg : 0x7fffffff;
+                    auto fetch = [&](int i, int h, int it) {
+                        const int m = m_w0 + i * 16 + rowv[it], n = n_w0 + h * CP + c8v[it];
+                        const int mc = FULL ? m : min(m, p.M - 1);
+                        // uniform base + 32-bit byte offset (every operand of this path is < 4 GB): one VGPR per address
+                        bvv = *(const f16x8*)((const char*)bp + (unsigned)(n * mbias) * 2u);
+                        if constexpr (RB) {
+                            const int g = rpg >= WM ? g0 + (mc >= gbound ? 1 : 0) : mc / rpg;
+                            rbv = *(const f16x8*)((const char*)rbp + (unsigned)(g * ldrb + n * mrb) * 2u);
+                        }
+                        if constexpr (R1) q1v = *(const f16x8*)((const char*)r1p + (unsigned)(mc * ld1 + n * m1) * 2u);
+                        if constexpr (R2) q2v = *(const f16x8*)((const char*)r2p + (unsigned)(mc * ld2 + n * m2) * 2u);
+                    };
+                    fetch(0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) {
+#pragma unroll
+                            for (int jj = 0; jj < CP / 16; ++jj) {
+                                *(f32x4*)(patch + frow * LDP + jj * 16 + fks * 4) = acc[i][h * (CP / 16) + jj];
+                                acc[i][h * (CP / 16) + jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            }
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int it = 0; it < ITERS; ++it) {
+                                const int row = rowv[it], c8 = c8v[it];
+                                const int m = m_w0 + i * 16 + row, n = n_w0 + h * CP + c8;
+                                const f32x4 lo = *(const f32x4*)(patch + row * LDP + c8);
+                                const f32x4 hi = *(const f32x4*)(patch + row * LDP + c8 + 4);
+                                float vv[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                                f16x8 o;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    vv[e] += (float)bvv[e];
+                                    if constexpr (RB) vv[e] += (float)rbv[e];
+                                }
+                                if (p.act == EW_ACT_SILU) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) vv[e] = ew_silu(vv[e]);
+                                }
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    float x = vv[e] * p.c_acc;
+                                    if constexpr (R1) x += p.c_r1 * (float)q1v[e];
+                                    if constexpr (R2) x += p.c_r2 * (float)q2v[e];
+                                    o[e] = (f16)x;
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (it + 1 < ITERS) fetch(i, h, it + 1);
+                                else if (h + 1 < NH) fetch(i, h + 1, 0);
+                                else if (i + 1 < FM) fetch(i + 1, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (is_live(it) && (FULL || m < p.M) && !(p.dbg & 1)) *(f16x8*)((char*)p.out + (unsigned)(m * p.ld_out + n) * 2u) = o;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                } else if constexpr ((EPI & 8) == 0) {
                     // Direct epilogue, no LDS: thanks to the permuted W staging (loader_new_tile) the two accumulator
                     // fragments (2q, 2q+1) of a lane are 8 consecutive output columns of row frow -> every operand access
                     // (bias, row-bias, residuals and their lo halves, output hi / lo) is ONE 16-byte access per lane, four
                     // lanes cover a 64-byte row segment, a wave instruction covers 16 rows x 64 B.
                     constexpr bool RB = EPI & 1, R1 = EPI & 2, R2 = EPI & 4, LO = EPI & 16;
-                    const f16* r1lp = p.r1_lo ? p.r1_lo : p.zero_page;
-                    const f16* r2lp = p.r2_lo ? p.r2_lo : p.zero_page;
+                    const int8_t* r1lp = p.r1_lo ? p.r1_lo : (const int8_t*)p.zero_page;      // lo8 companions (common.h): 1 byte / element
+                    const int8_t* r2lp = p.r2_lo ? p.r2_lo : (const int8_t*)p.zero_page;
                     const int m1l = p.r1_lo ? 1 : 0, m2l = p.r2_lo ? 1 : 0;
                     const int ld1l = p.r1_lo ? p.ld_r1 : 0, ld2l = p.r2_lo ? p.ld_r2 : 0;
                     constexpr int NQ = FN / 2;                  // 5 fragment pairs = 5 x 32 columns per wave tile
                     // vmcnt is in-order: a load issued after a store cannot be waited for without draining that store, so the
                     // operands of step s+1 are requested BEFORE the store of step s -- but after step s has consumed its own.
-                    f16x8 bvv, rbv, q1v, q2v, q1l, q2l;
+                    f16x8 bvv, rbv, q1v, q2v;
+                    u32x2 q1l, q2l;
                     const int rpg = p.rows_per_group;
                     const int g0 = min(m_w0, p.M - 1) / rpg;             // wave tiles past the last row must not index a group beyond the last
                     const int gbound = rpg >= WM ? (g0 + 1) * rpg : 0x7fffffff;
@@ -344,10 +477,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                         }
                         if constexpr (R1) q1v = *(const f16x8*)((const char*)r1p + (unsigned)(mc * ld1 + n * m1) * 2u);
                         if constexpr (R2) q2v = *(const f16x8*)((const char*)r2p + (unsigned)(mc * ld2 + n * m2) * 2u);
-                        if constexpr (R1 && LO) q1l = *(const f16x8*)((const char*)r1lp + (unsigned)(mc * ld1l + n * m1l) * 2u);
-                        if constexpr (R2 && LO) q2l = *(const f16x8*)((const char*)r2lp + (unsigned)(mc * ld2l + n * m2l) * 2u);
+                        if constexpr (R1 && LO) q1l = *(const u32x2*)((const char*)r1lp + (unsigned)(mc * ld1l + n * m1l));
+                        if constexpr (R2 && LO) q2l = *(const u32x2*)((const char*)r2lp + (unsigned)(mc * ld2l + n * m2l));
                     };
-                    const bool silu = p.act == EW_ACT_SILU, gelu = p.act == EW_ACT_GELU;
+                    const bool silu = p.act == EW_ACT_SILU, gelu = MODE == EW_A_DENSE && EPI == 0 && p.act == EW_ACT_GELU;
                     fetch(0, 0);
 #pragma unroll
                     for (int i = 0; i < FM; ++i) {
@@ -358,7 +491,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                             acc[i][2 * q] = (f32x4){0.f, 0.f, 0.f, 0.f};
                             acc[i][2 * q + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
                             float vv[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                            f16x8 o, ol;
+                            f16x8 o;
+                            u32x2 ol;
+                            int s8[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
                                 vv[e] += (float)bvv[e];
@@ -374,13 +509,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
                                 float x = vv[e] * p.c_acc;
-                                if constexpr (R1 && LO) x += p.c_r1 * ((float)q1v[e] + (float)q1l[e]);
+                                if constexpr (R1 && LO) x += p.c_r1 * ew_split_dec(q1v[e], ew_sbyte(q1l[e >> 2], e & 3));
                                 else if constexpr (R1) x += p.c_r1 * (float)q1v[e];
-                                if constexpr (R2 && LO) x += p.c_r2 * ((float)q2v[e] + (float)q2l[e]);
+                                if constexpr (R2 && LO) x += p.c_r2 * ew_split_dec(q2v[e], ew_sbyte(q2l[e >> 2], e & 3));
                                 else if constexpr (R2) x += p.c_r2 * (float)q2v[e];
                                 o[e] = (f16)x;
-                                if constexpr (LO) ol[e] = (f16)(x - (float)o[e]);
+                                if constexpr (LO) s8[e] = ew_split_enc(x, o[e]);
                             }
+                            if constexpr (LO) { ol[0] = ew_pack4(s8[0], s8[1], s8[2], s8[3]); ol[1] = ew_pack4(s8[4], s8[5], s8[6], s8[7]); }
                             __builtin_amdgcn_sched_barrier(0);
                             if (q + 1 < NQ) fetch(i, q + 1);
                             else if (i + 1 < FM) fetch(i + 1, 0);
@@ -388,7 +524,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                             if ((FULL || m < p.M) && !(p.dbg & 1)) {
                                 *(f16x8*)((char*)p.out + (unsigned)(m * p.ld_out + n) * 2u) = o;
                                 if constexpr (LO) {
-                                    if (p.out_lo) *(f16x8*)((char*)p.out_lo + (unsigned)(m * p.ld_out + n) * 2u) = ol;
+                                    if (p.out_lo) *(u32x2*)((char*)p.out_lo + (unsigned)(m * p.ld_out + n)) = ol;
                                 }
                             }
                         }
@@ -514,13 +650,17 @@ ew_status dispatch_epi3(const GemmP& p, hipStream_t s) {
 // true when generation 3 can run the problem AND is expected to be the faster choice (enough 256x320 tiles to fill the chip)
 bool ew_gemm3_wants(const GemmP& p) {
     if (p.N % BN != 0 || p.M < 4 * BM) return false;
+    // GELU (CLIP's fc1) is only compiled into the plain dense variant: the erf code in every epilogue cost the conv variants
+    // 11-28 spilled VGPRs (reloads inside the K loop, 4-10 % slower); anything else with GELU runs on generation 2
+    if (p.act == EW_ACT_GELU && (p.mode != EW_A_DENSE || p.rowbias || p.r1 || p.r2 || p.out_lo)) return false;
     // the epilogue addresses its row operands as uniform base + 32-bit byte offset
     const long long ld_max = max((long long)p.ld_out, max((long long)p.ld_r1, (long long)p.ld_r2));
     if ((long long)p.M * ld_max * 2 >= (1LL << 32)) return false;
     if (p.rowbias && ((long long)p.M / max(1, p.rows_per_group) + 2) * p.ld_rowbias * 2 >= (1LL << 32)) return false;
     // one tile column and a short K: 1800 tiles = 7.03 rounds over 256 CUs cost 8, and the residual-carrying epilogue is
     // store-bound anyway -- generation 2's 256x160 tiles (14.06 -> 15 rounds) measured 5-10 % faster there
-    if (p.mode == EW_A_DENSE && p.N == BN && p.K <= 1280 && (p.r1 || p.r2)) return false;
+    static const int short_rule = getenv("EW_G3_SHORT") ? atoi(getenv("EW_G3_SHORT")) : 0;     // A/B hook: 1 = gen3 also there
+    if (!short_rule && p.mode == EW_A_DENSE && p.N == BN && p.K <= 1280 && (p.r1 || p.r2)) return false;
     const long long tiles = (long long)ew_cdiv(p.M, BM) * (p.N / BN);
     return tiles >= 200;
 }

@@ -12,9 +12,9 @@ struct GemmP {
     const f16* r2;
     f16* out;
     const f16* zero_page;
-    const f16* r1_lo;   // split-fp16 residual stream companions (may be null)
-    const f16* r2_lo;
-    f16* out_lo;
+    const int8_t* r1_lo;   // split residual stream: lo8 companions, one byte per element, same element strides (may be null)
+    const int8_t* r2_lo;
+    int8_t* out_lo;
     int M, N, K;
     int c1, c2, lda, lda2, ld_out, ld_r1, ld_r2, ld_rowbias;
     int mode, n_img, h_in, w_in, h_out, w_out, stride, upsample;

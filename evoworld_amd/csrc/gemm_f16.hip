@@ -208,8 +208,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
                         const f16x4 b = *(const f16x4*)(p.r1 + (size_t)m * p.ld_r1 + n);
                         f32x4 bf = {(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
                         if (p.r1_lo) {
-                            const f16x4 l = *(const f16x4*)(p.r1_lo + (size_t)m * p.ld_r1 + n);
-                            bf += (f32x4){(float)l[0], (float)l[1], (float)l[2], (float)l[3]};
+                            const unsigned l = *(const unsigned*)(p.r1_lo + (size_t)m * p.ld_r1 + n);
+                            bf = (f32x4){ew_split_dec(b[0], ew_sbyte(l, 0)), ew_split_dec(b[1], ew_sbyte(l, 1)),
+                                         ew_split_dec(b[2], ew_sbyte(l, 2)), ew_split_dec(b[3], ew_sbyte(l, 3))};
                         }
                         v += p.c_r1 * bf;
                     }
@@ -217,16 +218,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmP p) {
                         const f16x4 b = *(const f16x4*)(p.r2 + (size_t)m * p.ld_r2 + n);
                         f32x4 bf = {(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
                         if (p.r2_lo) {
-                            const f16x4 l = *(const f16x4*)(p.r2_lo + (size_t)m * p.ld_r2 + n);
-                            bf += (f32x4){(float)l[0], (float)l[1], (float)l[2], (float)l[3]};
+                            const unsigned l = *(const unsigned*)(p.r2_lo + (size_t)m * p.ld_r2 + n);
+                            bf = (f32x4){ew_split_dec(b[0], ew_sbyte(l, 0)), ew_split_dec(b[1], ew_sbyte(l, 1)),
+                                         ew_split_dec(b[2], ew_sbyte(l, 2)), ew_split_dec(b[3], ew_sbyte(l, 3))};
                         }
                         v += p.c_r2 * bf;
                     }
                     const f16x4 oh = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
                     *(f16x4*)(p.out + (size_t)m * p.ld_out + n) = oh;
                     if (p.out_lo)
-                        *(f16x4*)(p.out_lo + (size_t)m * p.ld_out + n) = (f16x4){(f16)(v[0] - (float)oh[0]), (f16)(v[1] - (float)oh[1]),
-                                                                                 (f16)(v[2] - (float)oh[2]), (f16)(v[3] - (float)oh[3])};
+                        *(unsigned*)(p.out_lo + (size_t)m * p.ld_out + n) =
+                            ew_pack4(ew_split_enc(v[0], oh[0]), ew_split_enc(v[1], oh[1]), ew_split_enc(v[2], oh[2]), ew_split_enc(v[3], oh[3]));
                 }
             }
         } else {
@@ -334,7 +336,7 @@ extern "C" ew_status ew_gemm_f16(const ew_gemm_args* a, void* stream) {
     p.a = (const f16*)a->a; p.a2 = (const f16*)a->a2; p.w = (const f16*)a->w; p.bias = (const f16*)a->bias;
     p.rowbias = (const f16*)a->rowbias; p.r1 = (const f16*)a->r1; p.r2 = (const f16*)a->r2; p.out = (f16*)a->out;
     p.zero_page = (const f16*)a->zero_page;
-    p.r1_lo = (const f16*)a->r1_lo; p.r2_lo = (const f16*)a->r2_lo; p.out_lo = (f16*)a->out_lo;
+    p.r1_lo = (const int8_t*)a->r1_lo; p.r2_lo = (const int8_t*)a->r2_lo; p.out_lo = (int8_t*)a->out_lo;
     p.conv_shift = a->conv_shift;
     p.M = a->M; p.N = a->N; p.K = taps * (a->c1 + a->c2);
     p.c1 = a->c1; p.c2 = a->c2; p.lda = a->lda; p.lda2 = a->lda2; p.ld_out = a->ld_out; p.ld_r1 = a->ld_r1; p.ld_r2 = a->ld_r2; p.ld_rowbias = a->ld_rowbias;

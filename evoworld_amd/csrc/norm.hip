@@ -17,7 +17,7 @@ namespace {
 //   stage 2 (gn_finalize_kernel): one wave per (slab, group): lanes own channels, loop over the chunks in order, then a
 //     fixed shuffle tree: mean_g, var_g (two-level: per-channel mean / M2, then across the group's channels).
 // The chunking depends on (rows, n_slabs) only, so the two sources of a virtual channel concat share one partial buffer.
-// x_lo (may be null): lo half of a split-fp16 residual stream, x = hi + lo.
+// x_lo (may be null): lo8 companion of a split residual stream (common.h: one byte per element, same element strides).
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ inline int gn_chunks(int n_slabs, int rows) {
     int want = (640 + n_slabs - 1) / n_slabs;                  // ~2.5 blocks per CU over the whole launch
@@ -27,7 +27,7 @@ __host__ __device__ inline int gn_chunks(int n_slabs, int rows) {
     return want < 1 ? 1 : want;
 }
 
-__global__ void gn_stats_kernel(const f16* __restrict__ x, const f16* __restrict__ x_lo, float* __restrict__ part,
+__global__ void gn_stats_kernel(const f16* __restrict__ x, const int8_t* __restrict__ x_lo, float* __restrict__ part,
                                 float* __restrict__ pivot, int rows, int C_src, int c_off, int C_tot, int VPP, int PL,
                                 int rows_per_block) {
     extern __shared__ float lds[];  // [PL][2][C_src]
@@ -39,42 +39,43 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, const f16* __restrict
     float s[8], q[8], piv[8];
     const size_t slab_off = ((size_t)slab * rows) * C_src + v * 8;
     const f16* base = x + slab_off;
-    const f16* base_lo = x_lo ? x_lo + slab_off : nullptr;
+    const int8_t* base_lo = x_lo ? x_lo + slab_off : nullptr;
     {
         const f16x8 p0 = *(const f16x8*)base;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; piv[e] = (float)p0[e]; }
-        if (base_lo) {
-            const f16x8 p1 = *(const f16x8*)base_lo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) piv[e] += (float)p1[e];
-        }
+        if (base_lo) ew_split_dec8(p0, *(const u32x2*)base_lo, piv);
     }
     // eight independent 16-byte loads in flight per thread (one dependent load per iteration ran at 3.3 TB/s, four at 3.8)
     int r = r0 + pl;
     if (base_lo) {
         for (; r + 3 * PL < r1; r += 4 * PL) {
-            f16x8 val[4], vlo[4];
+            f16x8 val[4];
+            u32x2 vlo[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 val[u] = *(const f16x8*)(base + (size_t)(r + u * PL) * C_src);
-                vlo[u] = *(const f16x8*)(base_lo + (size_t)(r + u * PL) * C_src);
+                vlo[u] = *(const u32x2*)(base_lo + (size_t)(r + u * PL) * C_src);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u) {
+                float xv[8];
+                ew_split_dec8(val[u], vlo[u], xv);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float f = ((float)val[u][e] + (float)vlo[u][e]) - piv[e];
+                    const float f = xv[e] - piv[e];
                     s[e] += f;
                     q[e] += f * f;
                 }
+            }
         }
         for (; r < r1; r += PL) {
             const f16x8 val = *(const f16x8*)(base + (size_t)r * C_src);
-            const f16x8 vlo = *(const f16x8*)(base_lo + (size_t)r * C_src);
+            float xv[8];
+            ew_split_dec8(val, *(const u32x2*)(base_lo + (size_t)r * C_src), xv);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float f = ((float)val[e] + (float)vlo[e]) - piv[e];
+                const float f = xv[e] - piv[e];
                 s[e] += f;
                 q[e] += f * f;
             }
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 // into scale[8], shift[8]; the row loop is load, 8 fma (+SiLU), store.  (The first version re-derived (row, column, slab,
 // group) with 64-bit divisions for every vector and ran at 2.8 TB/s.)
 template <bool LO>
-__global__ void gn_apply_kernel(const f16* __restrict__ x, const f16* __restrict__ x_lo, const float* __restrict__ stats,
+__global__ void gn_apply_kernel(const f16* __restrict__ x, const int8_t* __restrict__ x_lo, const float* __restrict__ stats,
                                 const f16* __restrict__ gamma, const f16* __restrict__ beta, f16* __restrict__ y, int rows,
                                 int C_src, int c_off, int C_tot, int groups, float eps, int silu, int VPP, int PL,
                                 int rows_per_block) {
@@ -212,23 +213,25 @@ __global__ void gn_apply_kernel(const f16* __restrict__ x, const f16* __restrict
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(rows, r0 + rows_per_block);
     const f16* xin = x + ((size_t)slab * rows) * C_src + c;
-    const f16* xlo = LO ? x_lo + ((size_t)slab * rows) * C_src + c : nullptr;
+    const int8_t* xlo = LO ? x_lo + ((size_t)slab * rows) * C_src + c : nullptr;
     f16* yout = y + ((size_t)slab * rows) * C_tot + c_off + c;
     int r = r0 + pl;
     for (; r + 3 * PL < r1; r += 4 * PL) {
-        f16x8 val[4], vlo[4];
+        f16x8 val[4];
+        u32x2 vlo[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             val[u] = *(const f16x8*)(xin + (size_t)(r + u * PL) * C_src);
-            if constexpr (LO) vlo[u] = *(const f16x8*)(xlo + (size_t)(r + u * PL) * C_src);
+            if constexpr (LO) vlo[u] = *(const u32x2*)(xlo + (size_t)(r + u * PL) * C_src);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             f16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float xv = (float)val[u][e];
-                if constexpr (LO) xv += (float)vlo[u][e];
+                float xv;
+                if constexpr (LO) xv = ew_split_dec(val[u][e], ew_sbyte(vlo[u][e >> 2], e & 3));
+                else xv = (float)val[u][e];
                 float f = (xv - shift[e]) * scale[e] * (float)gm[e] + (float)bt[e];
                 if (silu) f = ew_silu(f);
                 o[e] = (f16)f;
@@ -238,13 +241,14 @@ __global__ void gn_apply_kernel(const f16* __restrict__ x, const f16* __restrict
     }
     for (; r < r1; r += PL) {
         const f16x8 val = *(const f16x8*)(xin + (size_t)r * C_src);
-        f16x8 vlo;
-        if constexpr (LO) vlo = *(const f16x8*)(xlo + (size_t)r * C_src);
+        u32x2 vlo;
+        if constexpr (LO) vlo = *(const u32x2*)(xlo + (size_t)r * C_src);
         f16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float xv = (float)val[e];
-            if constexpr (LO) xv += (float)vlo[e];
+            float xv;
+            if constexpr (LO) xv = ew_split_dec(val[e], ew_sbyte(vlo[e >> 2], e & 3));
+            else xv = (float)val[e];
             float f = (xv - shift[e]) * scale[e] * (float)gm[e] + (float)bt[e];
             if (silu) f = ew_silu(f);
             o[e] = (f16)f;
@@ -258,9 +262,9 @@ __global__ void gn_apply_kernel(const f16* __restrict__ x, const f16* __restrict
 // two-pass (mean, then centred variance) on registers.
 // ---------------------------------------------------------------------------------------------
 template <int NV, int RPW>
-__global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, const f16* __restrict__ x_lo,
+__global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, const int8_t* __restrict__ x_lo,
                                                  const f16* __restrict__ addvec, int rpg, f16* __restrict__ x_out,
-                                                 f16* __restrict__ x_out_lo, const f16* __restrict__ gamma,
+                                                 int8_t* __restrict__ x_out_lo, const f16* __restrict__ gamma,
                                                  const f16* __restrict__ beta, f16* __restrict__ y, int rows, int C,
                                                  float eps) {
     // a wave owns RPW consecutive rows and issues all their loads before reducing any of them: at C = 320 a row is only
@@ -270,7 +274,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, cons
     if (row0 >= rows) return;
     const int VPP = C / 8;
     float v[RPW][NV][8];
-    f16x8 raw[RPW][NV], add[RPW][NV], rlo[RPW][NV];
+    f16x8 raw[RPW][NV], add[RPW][NV];
+    u32x2 rlo[RPW][NV];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int row = min(row0 + r, rows - 1);
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, cons
             const int vi = lane + k * 64;
             if (vi < VPP) {
                 raw[r][k] = *(const f16x8*)(x + (size_t)row * C + vi * 8);
-                if (x_lo) rlo[r][k] = *(const f16x8*)(x_lo + (size_t)row * C + vi * 8);
+                if (x_lo) rlo[r][k] = *(const u32x2*)(x_lo + (size_t)row * C + vi * 8);
                 if (addvec) add[r][k] = *(const f16x8*)(addvec + (size_t)(row / rpg) * C + vi * 8);
             }
         }
@@ -299,25 +304,28 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, cons
         for (int k = 0; k < NV; ++k) {
             const int vi = lane + k * 64;
             if (vi < VPP) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[r][k][e] = (float)raw[r][k][e];
                 if (x_lo) {
+                    ew_split_dec8(raw[r][k], rlo[r][k], v[r][k]);                        // split stream: x = (hi, lo8)
+                } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[r][k][e] += (float)rlo[r][k][e];      // split-fp16 stream: x = hi + lo
+                    for (int e = 0; e < 8; ++e) v[r][k][e] = (float)raw[r][k][e];
                 }
                 if (addvec) {
-                    f16x8 xo, xl;
+                    f16x8 xo;
+                    int s8[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         // what is normalised IS the residual stream the block continues from: fp16(x + add), or its
-                        // hi + lo split when the caller keeps the lo half (x_out_lo)
+                        // (hi, lo8) split when the caller keeps the lo half (x_out_lo)
                         const float sum = v[r][k][e] + (float)add[r][k][e];
                         xo[e] = (f16)sum;
-                        xl[e] = (f16)(sum - (float)xo[e]);
-                        v[r][k][e] = !x_out ? sum : (x_out_lo ? (float)xo[e] + (float)xl[e] : (float)xo[e]);   // not materialised: exact
+                        s8[e] = ew_split_enc(sum, xo[e]);
+                        v[r][k][e] = !x_out ? sum : (x_out_lo ? ew_split_dec(xo[e], s8[e]) : (float)xo[e]);   // not materialised: exact
                     }
                     if (x_out && live) *(f16x8*)(x_out + (size_t)row * C + vi * 8) = xo;
-                    if (x_out_lo && live) *(f16x8*)(x_out_lo + (size_t)row * C + vi * 8) = xl;
+                    if (x_out_lo && live)
+                        *(u32x2*)(x_out_lo + (size_t)row * C + vi * 8) =
+                            (u32x2){ew_pack4(s8[0], s8[1], s8[2], s8[3]), ew_pack4(s8[4], s8[5], s8[6], s8[7])};
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sum += v[r][k][e];
@@ -385,7 +393,7 @@ extern "C" ew_status ew_groupnorm_stats_f16(const void* x, const void* x_lo, flo
     dim3 grid(w.chunks, n_slabs);
     const size_t lds = (size_t)PL * 2 * C_src * sizeof(float);
     EW_REQUIRE(lds <= 64 * 1024, "ew_groupnorm_stats_f16: C_src too large for the LDS combine");
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(VPP * PL), lds, (hipStream_t)stream, (const f16*)x, (const f16*)x_lo,
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(VPP * PL), lds, (hipStream_t)stream, (const f16*)x, (const int8_t*)x_lo,
                        w.part, w.pivot, rows, C_src, c_off, C_tot, VPP, PL, rpb);
     return ew_check_launch("ew_groupnorm_stats_f16");
 }
@@ -414,10 +422,10 @@ extern "C" ew_status ew_groupnorm_apply_f16(const void* x, const void* x_lo, con
     const GnWs w = gn_ws((float*)ws, n_slabs, rows, C_tot);
     dim3 grid(ew_cdiv(rows, rpb), n_slabs);
     if (x_lo)
-        hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(VPP * PL), 0, (hipStream_t)stream, (const f16*)x, (const f16*)x_lo,
+        hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(VPP * PL), 0, (hipStream_t)stream, (const f16*)x, (const int8_t*)x_lo,
                            w.stats, (const f16*)gamma, (const f16*)beta, (f16*)y, rows, C_src, c_off, C_tot, groups, eps, silu, VPP, PL, rpb);
     else
-        hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(VPP * PL), 0, (hipStream_t)stream, (const f16*)x, (const f16*)nullptr,
+        hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(VPP * PL), 0, (hipStream_t)stream, (const f16*)x, (const int8_t*)nullptr,
                            w.stats, (const f16*)gamma, (const f16*)beta, (f16*)y, rows, C_src, c_off, C_tot, groups, eps, silu, VPP, PL, rpb);
     return ew_check_launch("ew_groupnorm_apply_f16");
 }
@@ -434,8 +442,8 @@ extern "C" ew_status ew_layernorm_f16(const void* x, const void* x_lo, const voi
     hipStream_t s = (hipStream_t)stream;
     const int rpg = rows_per_group >= 1 ? rows_per_group : 1;
 #define LN_LAUNCH(NV, RPW)                                                                                         \
-    hipLaunchKernelGGL((ln_kernel<NV, RPW>), dim3(ew_cdiv(rows, 4 * RPW)), block, 0, s, (const f16*)x, (const f16*)x_lo, \
-                       (const f16*)addvec, rpg, (f16*)x_out, (f16*)x_out_lo, (const f16*)gamma, (const f16*)beta, (f16*)y, rows, C, eps)
+    hipLaunchKernelGGL((ln_kernel<NV, RPW>), dim3(ew_cdiv(rows, 4 * RPW)), block, 0, s, (const f16*)x, (const int8_t*)x_lo, \
+                       (const f16*)addvec, rpg, (f16*)x_out, (int8_t*)x_out_lo, (const f16*)gamma, (const f16*)beta, (f16*)y, rows, C, eps)
     if (nv == 1) LN_LAUNCH(1, 4);
     else if (nv == 2) LN_LAUNCH(2, 4);
     else if (nv == 3) LN_LAUNCH(3, 2);

@@ -39,9 +39,11 @@ def zero_page(device):
 
 
 class Res:
-    """A residual-stream tensor carried as split fp16: value = hi + lo (lo = fp16(x - fp16(x)), ~21 mantissa bits; None when
-    the stream is kept in plain fp16).  The reference runs the stream in fp32 (unified_loop_consistency.py:188); consumers
-    that need an fp16 MFMA operand read `hi` alone, the residual epilogues and the norms read both halves."""
+    """A residual-stream tensor carried split: hi = fp16(x) plus an int8 companion `lo` (one byte per element:
+    bits(x) ~= bits(float(hi)) + 32 * lo on the fp32 bit patterns, ~19 mantissa bits in 3 bytes; include/evoworld_hip.h,
+    ew_gemm_args), or lo = None when the stream is kept in plain fp16.  The reference runs the stream in fp32
+    (unified_loop_consistency.py:188); consumers that need an fp16 MFMA operand read `hi` alone, the residual epilogues and
+    the norms read both."""
     __slots__ = ("hi", "lo")
 
     def __init__(self, hi, lo=None):
@@ -50,10 +52,20 @@ class Res:
     @classmethod
     def empty(cls, rows, C, device, split):
         hi = torch.empty(rows, C, dtype=torch.float16, device=device)
-        return cls(hi, torch.empty_like(hi) if split else None)
+        return cls(hi, torch.empty(rows, C, dtype=torch.int8, device=device) if split else None)
+
+    @classmethod
+    def from_float(cls, x):
+        """fp32 tensor -> split form (host-side twin of the kernels' encoder: tests, debugging taps)."""
+        x = x.float().contiguous()
+        hi = x.half()
+        d = (x.view(torch.int32) - hi.float().view(torch.int32) + 16) >> 5
+        return cls(hi, d.clamp_(-128, 127).to(torch.int8))
 
     def float(self):
-        return self.hi.float() if self.lo is None else self.hi.float() + self.lo.float()
+        if self.lo is None:
+            return self.hi.float()
+        return (self.hi.float().contiguous().view(torch.int32) + (self.lo.to(torch.int32) << 5)).view(torch.float32)
 
 
 def _hl(x):

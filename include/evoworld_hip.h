@@ -27,7 +27,7 @@ typedef int ew_status;
 #define EW_ERR_UNSUPPORTED (-2)
 #define EW_ERR_HIP (-3)
 
-#define EW_ABI_VERSION 3
+#define EW_ABI_VERSION 4
 int ew_abi_version(void);
 const char* ew_last_error(void);
 
@@ -77,10 +77,12 @@ typedef struct ew_gemm_args {
     int rows_per_group; /* rowbias group size in rows (>=1) */
     int act;            /* EW_ACT_* */
     float c_acc, c_r1, c_r2;
-    /* Split-fp16 residual stream (ABI 2): a residual-stream tensor x is carried as hi = fp16(x) plus lo = fp16(x - hi)
-     * (~21 mantissa bits; the reference keeps the stream in fp32, unified_loop_consistency.py:188).  Consumers that only
-     * need an fp16 operand read `hi` alone.  r1_lo / r2_lo (same strides as r1 / r2) are added to r1 / r2 in fp32;
-     * out_lo (stride ld_out) receives fp16(v - fp16(v)).  Any of them may be NULL; not available with GEGLU. */
+    /* Split residual stream (ABI 4): a residual-stream tensor x is carried as hi = fp16(x) (round to nearest even) plus an
+     * int8 companion lo8, ONE byte per element with the same element strides: bits(x) ~= bits((float)hi) + 32 * lo8 on the
+     * fp32 bit patterns, i.e. 8 more mantissa bits (~19 in all; the reference keeps the stream in fp32,
+     * unified_loop_consistency.py:188) for 3 bytes per element.  Consumers that only need an fp16 operand read `hi` alone.
+     * r1_lo / r2_lo (element strides ld_r1 / ld_r2) refine r1 / r2; out_lo (element stride ld_out) receives the lo8 of the
+     * fp32 result.  Any of them may be NULL; not available with GEGLU.  (ABI 2-3 carried a second fp16 plane instead.) */
     const void* r1_lo;
     const void* r2_lo;
     void* out_lo;
@@ -102,8 +104,8 @@ void ew_set_gemm_debug(int flags);   /* measurement-only switches (bit0: skip st
 /* GroupNorm statistics + apply, channels-last fp16, over a (virtual) channel concat.
  * The normalised tensor has C_tot channels in `groups` groups; a stats/apply call handles the C_src channels
  * [c_off, c_off+C_src) that live in tensor `x` ([n_slabs*rows, C_src]); a skip-concat input is covered by
- * two calls (one per source) -- groups may straddle the seam.  x_lo (may be NULL) is the lo half of a
- * split-fp16 residual stream (x = hi + lo, see ew_gemm_args).
+ * two calls (one per source) -- groups may straddle the seam.  x_lo (may be NULL) is the lo8 companion of a
+ * split residual stream (int8, one byte per element, see ew_gemm_args).
  * Statistics are DETERMINISTIC and cancellation-safe (no atomics): ew_groupnorm_stats_f16 writes per-(slab, row chunk,
  * channel) sums of (x - K_c) and (x - K_c)^2 shifted by the pivot K_c = x[slab, row 0, c] into the workspace;
  * ew_groupnorm_finalize (one call per GroupNorm, after the stats calls of all its sources) reduces them in a fixed
@@ -122,9 +124,9 @@ ew_status ew_groupnorm_apply_f16(const void* x, const void* x_lo, const float* w
                                  void* y, int n_slabs, int rows, int C_src, int c_off, int C_tot, int groups, float eps,
                                  int silu, void* stream);
 
-/* LayerNorm over the last dim (fp16 in/out, fp32 two-pass statistics).  x_lo (may be NULL): lo half of a split-fp16
- * residual stream.  Optional fused pre-add: x' = x + addvec[row / rows_per_group][:] is what gets normalised, and x' is
- * written to x_out (fp16) -- plus its rounding remainder to x_out_lo when non-NULL -- (the time_pos_embed add in
+/* LayerNorm over the last dim (fp16 in/out, fp32 two-pass statistics).  x_lo (may be NULL): lo8 companion of a split
+ * residual stream (int8).  Optional fused pre-add: x' = x + addvec[row / rows_per_group][:] is what gets normalised, and x' is
+ * written to x_out (fp16) -- plus its lo8 companion to x_out_lo when non-NULL -- (the time_pos_embed add in
  * TransformerSpatioTemporalModel).  C % 8 == 0, C <= 2048.
  * Replaces torch.nn.LayerNorm in Basic/TemporalBasicTransformerBlock (diffusers, via unet_plucker.py:13). */
 ew_status ew_layernorm_f16(const void* x, const void* x_lo, const void* addvec, int rows_per_group, void* x_out,
@@ -164,8 +166,8 @@ ew_status ew_euler_cfg_step(const void* eps, int ld_eps, float* latents, const f
 
 /* Row softmax for the VAE's single-head attention (AutoencoderKLTemporalDecoder mid blocks, head_dim 512: diffusers
  * Attention with upcast_softmax; pipeline_evoworld.py:307-328,358-385 via vae.encode / vae.decode): the [S,S] score matrix
- * of one frame comes out of ew_gemm_f16 as split fp16 (hi + lo, so no fp16 rounding before the exponential);
- * out[r][:] = softmax(hi[r][:] + lo[r][:]) in fp32, stored fp16.  lo may be NULL.  cols % 8 == 0. */
+ * of one frame comes out of ew_gemm_f16 split (hi fp16 + lo8 int8, so no fp16 rounding before the exponential);
+ * out[r][:] = softmax(decode(hi[r][:], lo[r][:])) in fp32, stored fp16.  lo (element stride ld) may be NULL.  cols % 8 == 0. */
 ew_status ew_softmax_rows_f16(const void* hi, const void* lo, void* out, long long rows, int cols, long long ld, void* stream);
 
 /* TemporalDecoder.time_conv_out: Conv3d(C, C, (3,1,1), padding (1,0,0)) over fp32 frames x [B,T,C,HW] (C <= 4; w [C,C,3],

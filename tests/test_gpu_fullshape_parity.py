@@ -60,9 +60,8 @@ def test_groupnorm_temporal_slab_mean_over_std(ops, ratio, split):
     gam, bet = torch.randn(C, generator=_g(4)) * 0.2 + 1, torch.randn(C, generator=_g(5)) * 0.1
     xh = x.half().to(DEV)
     if split:
-        lo = (x.to(DEV) - xh.float()).half()
-        src = ops.Res(xh, lo)
-        xf = xh.float() + lo.float()
+        src = ops.Res.from_float(x.to(DEV))
+        xf = src.float()
     else:
         src, xf = xh, xh.float()
     out = ops.groupnorm([src], gam.half().to(DEV), bet.half().to(DEV), n, rows, 1e-5, True)
@@ -113,15 +112,15 @@ def test_residual_gemm_level0_split_stream(ops):
     w = (torch.randn(N, K, generator=_g(13)) / math.sqrt(K)).half().to(DEV)
     b = (torch.randn(N, generator=_g(14)) * 0.1).half().to(DEV)
     r = torch.randn(M, N, generator=_g(15)) * 3
-    rh = r.half().to(DEV)
-    rl = (r.to(DEV) - rh.float()).half()
+    r1 = ops.Res.from_float(r.to(DEV))
+    rf = r1.float()
     out = ops.Res.empty(M, N, DEV, True)
-    ops.gemm(x, w, out, M=M, N=N, c1=K, lda=K, bias=b, r1=ops.Res(rh, rl), ld_r1=N)
+    ops.gemm(x, w, out, M=M, N=N, c1=K, lda=K, bias=b, r1=r1, ld_r1=N)
     worst_hi = worst = 0.0
     for m0 in range(0, M, 115200):
         sl = slice(m0, m0 + 115200)
-        ref = x[sl].float() @ w.float().T + b.float() + rh[sl].float() + rl[sl].float()
-        worst = max(worst, rel_l2((out.hi[sl].float() + out.lo[sl].float()).cpu(), ref.cpu()))
+        ref = x[sl].float() @ w.float().T + b.float() + rf[sl]
+        worst = max(worst, rel_l2(ops.Res(out.hi[sl], out.lo[sl]).float().cpu(), ref.cpu()))
         worst_hi = max(worst_hi, rel_l2(out.hi[sl].float().cpu(), ref.cpu()))
     print(f"split residual GEMM: hi+lo rel-L2 {worst:.3e}, hi only {worst_hi:.3e}")
     assert worst < 2e-5 and worst_hi < 4e-4

@@ -180,10 +180,8 @@ def test_groupnorm_split_stream_concat(ops):
     g, b = rnd(C, seed=3) * 0.2 + 1, rnd(C, seed=4) * 0.1
     src, full = [], []
     for x in xs:
-        hi = x.half().to(DEV)
-        lo = (x.to(DEV) - hi.float()).half()
-        src.append(ops.Res(hi, lo))
-        full.append(hi.float() + lo.float())
+        src.append(ops.Res.from_float(x.to(DEV)))
+        full.append(src[-1].float())
     out = ops.groupnorm(src, g.half().to(DEV), b.half().to(DEV), n, rows, 1e-5, True)
     xc = torch.cat(full, 1).reshape(n, rows, C).permute(0, 2, 1)
     ref = F.silu(F.group_norm(xc, 32, g.half().float().to(DEV), b.half().float().to(DEV), 1e-5)).permute(0, 2, 1).reshape(n * rows, C)
@@ -205,8 +203,9 @@ def test_gemm_split_residual_epilogues(ops):
                 b = rnd(N, seed=3).half().to(DEV)
                 r1f, r2f = rnd(M, N, seed=5) * 3, rnd(M, N, seed=6) * 3
                 r1h, r2h = r1f.half().to(DEV), r2f.half().to(DEV)
-                r1 = ops.Res(r1h, (r1f.to(DEV) - r1h.float()).half())
-                r2 = ops.Res(r2h, (r2f.to(DEV) - r2h.float()).half())
+                r1, r2 = ops.Res.from_float(r1f.to(DEV)), ops.Res.from_float(r2f.to(DEV))
+                assert torch.equal(r1.hi, r1h) and torch.equal(r2.hi, r2h)          # hi is the plain fp16 rounding
+                assert rel_l2(r1.float().cpu(), r1f) < 2e-6                         # ~19 mantissa bits in 3 bytes
                 out = ops.Res.empty(M, N, DEV, True)
                 ops.gemm(x, w, out, M=M, N=N, c1=K, lda=K, bias=b, r1=r1, ld_r1=N, r2=r2, ld_r2=N, c_acc=0.4, c_r1=0.6, c_r2=-1.5)
                 ref = 0.4 * (x.float() @ w.float().T + b.float()) + 0.6 * r1.float() - 1.5 * r2.float()
@@ -238,11 +237,11 @@ def test_layernorm(ops, rows, C):
     xs = (xh.float() + av.float()[torch.arange(rows, device=DEV) // rpg]).half()
     assert torch.equal(xo, xs)
     assert rel_l2(out2.float().cpu(), F.layer_norm(xs.float(), (C,), gh.float(), bh.float(), 1e-5).cpu()) < 1e-3
-    # split-fp16 stream in and out
-    lo = (x.to(DEV) - xh.float()).half()
+    # split stream (hi, lo8) in and out
+    xs3 = ops.Res.from_float(x.to(DEV))
     xo3 = ops.Res.empty(rows, C, DEV, True)
-    out3 = ops.layernorm(ops.Res(xh, lo), gh, bh, addvec=av, rows_per_group=rpg, x_out=xo3)
-    full = xh.float() + lo.float() + av.float()[torch.arange(rows, device=DEV) // rpg]
+    out3 = ops.layernorm(xs3, gh, bh, addvec=av, rows_per_group=rpg, x_out=xo3)
+    full = xs3.float() + av.float()[torch.arange(rows, device=DEV) // rpg]
     assert rel_l2(xo3.float().cpu(), full.cpu()) < 2e-6
     assert rel_l2(out3.float().cpu(), F.layer_norm(full, (C,), gh.float(), bh.float(), 1e-5).cpu()) < 4e-4
 

@@ -22,10 +22,10 @@ def test_softmax_rows_split_scores():
     from evoworld_amd import ops
     R, C = 300, 1024
     s = torch.randn(R, C, generator=_g(0)) * 6
-    hi = s.half().to(DEV)
-    lo = (s.to(DEV) - hi.float()).half()
-    p = ops.softmax_rows(ops.Res(hi, lo))
-    ref = torch.softmax(hi.float() + lo.float(), dim=-1)
+    sr = ops.Res.from_float(s.to(DEV))
+    hi = sr.hi
+    p = ops.softmax_rows(sr)
+    ref = torch.softmax(sr.float(), dim=-1)
     assert rel_l2(p.float().cpu(), ref.cpu()) < 4e-4
     p1 = ops.softmax_rows(hi)
     assert rel_l2(p1.float().cpu(), torch.softmax(hi.float(), -1).cpu()) < 4e-4
