@@ -16,7 +16,7 @@ ABI_VERSION = 4
 
 # every symbol declared in include/evoworld_hip.h
 SYMBOLS = [
-    "ew_abi_version", "ew_last_error", "ew_gemm_f16", "ew_set_gemm_generation", "ew_get_gemm_generation", "ew_set_gemm_debug", "ew_gemm_last_kernel", "ew_groupnorm_workspace_floats", "ew_groupnorm_stats_f16", "ew_groupnorm_finalize", "ew_groupnorm_apply_f16",
+    "ew_abi_version", "ew_last_error", "ew_gemm_f16", "ew_set_gemm_generation", "ew_get_gemm_generation", "ew_set_gemm_debug", "ew_gemm_last_kernel", "ew_gemm_streamk_status", "ew_groupnorm_workspace_floats", "ew_groupnorm_stats_f16", "ew_groupnorm_finalize", "ew_groupnorm_apply_f16",
     "ew_layernorm_f16", "ew_attn_spatial_f16", "ew_attn_temporal_f16", "ew_nchw_f32_to_nhwc_f16",
     "ew_nhwc_f16_to_nchw_f32", "ew_softmax_rows_f16", "ew_time_conv3_f32", "ew_euler_cfg_step", "ew_plucker_embed", "ew_cube2equi_gather",
     "ew_depth_unproject", "ew_select_workspace_bytes", "ew_select_kth_f32", "ew_filter_compact_workspace_bytes",
@@ -106,6 +106,8 @@ def load():
     lib.ew_set_gemm_generation.argtypes = [c_int]
     lib.ew_set_gemm_generation.restype = None
     lib.ew_get_gemm_generation.restype = c_int
+    lib.ew_gemm_streamk_status.argtypes = []
+    lib.ew_gemm_streamk_status.restype = c_int
     lib.ew_set_gemm_debug.argtypes = [c_int]
     lib.ew_set_gemm_debug.restype = None
     for name, argtypes in sig.items():

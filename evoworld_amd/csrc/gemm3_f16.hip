@@ -44,6 +44,7 @@ constexpr int NSTEP = 2 * FN;                                          // 20 ste
 #ifndef EW_G3_DIST
 #define EW_G3_DIST 2
 #endif
+constexpr int ITEMS_BYTES = 8192;                                      // work-item table: up to 512 (tile, k0, k1) entries per block
 constexpr int PD = EW_G3_DIST;                                         // W fragments are read PD steps ahead of their MFMAs (ring of 4)
 constexpr int BAR_STEP = NSTEP - 1 - PD;                               // barrier after the step that issues the tile's last read
 
@@ -66,7 +67,7 @@ __device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, in
 }
 
 template <int MODE, int EPI>
-__global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
+__global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const SkP sk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // epilogue family: GEGLU (EPI & 8) and the conv modes without lo8 operands go through a wave-private LDS patch; dense GEMMs
     // and everything that carries the split residual stream use the LDS-free direct epilogue (permuted W staging)
@@ -80,23 +81,57 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
     const int G = gridDim.x;
     const int total_tiles = p.tiles_m * p.tiles_n;
     const int seq0 = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    const int n_my = seq0 < total_tiles ? (total_tiles - 1 - seq0) / G + 1 : 0;
     const int nk = p.K / BK;
-    const int V = n_my * nk;                                           // K-tile stream length of this block
+    // Work items of this block: [stream-K items] then [data-parallel tiles i*G + seq0].  With the stream-K tail on, the last
+    // sk_tiles tiles (ids >= sk_dp_rounds*G) form one stream of sk_tiles*nk K-tile units cut into G equal ranges; range seq0
+    // starts with the TAIL of a tile (k0 > 0: this block contributes its partial accumulators to slot seq0 -- first thing it
+    // does), continues with whole tiles and ends with the HEAD of a tile (k1 < nk: this block finishes that tile with the
+    // partial of block seq0+1 -- which that block wrote at its very start, so the wait is short by construction).
+    const int sk_U = sk.tiles * nk;
+    const int sk_u0 = sk.tiles ? (int)((long long)seq0 * sk_U / G) : 0;
+    const int sk_u1 = sk.tiles ? (int)((long long)(seq0 + 1) * sk_U / G) : 0;
+    const int sk_tA = sk_u0 / nk, sk_kA = sk_u0 - sk_tA * nk, sk_tB = sk_u1 / nk, sk_kB = sk_u1 - sk_tB * nk;
+    const int n_sk = sk.tiles ? (sk_tB - sk_tA) + (sk_kB > 0 ? 1 : 0) : 0;
+    const int sk_id0 = sk.dp_rounds * G;
+    const int n_dp = sk.tiles ? sk.dp_rounds : (seq0 < total_tiles ? (total_tiles - 1 - seq0) / G + 1 : 0);
+    const int V = (sk_u1 - sk_u0) + n_dp * nk;                         // K-tile stream length of this block
     if (V == 0) return;
+    // The items (tile id, first K-tile, end K-tile) go into a small LDS table behind the two stages: the loader and the MFMA
+    // stream each read one entry per tile.  (Computing them in place -- a branchy expression inside the loader lambda -- kept
+    // hipcc from promoting the lambdas' captured state to registers: 600 bytes of scratch per lane.)
+    int* const items = (int*)(smem + 2 * STAGE);
+    for (int w = threadIdx.x; w < n_sk + n_dp; w += 64 * NW) {
+        int id, k0 = 0, k1 = nk;
+        if (w < n_sk) {
+            const int t = sk_tA + w;
+            id = sk_id0 + t;
+            if (w == 0) k0 = sk_kA;
+            if (t == sk_tB) k1 = sk_kB;
+        } else {
+            id = (w - n_sk) * G + seq0;
+        }
+        *(int4*)(items + 4 * w) = make_int4(id, k0, k1, 0);
+    }
+    __syncthreads();
+#define EW3_GET_ITEM(w_, id_, k0_, k1_)                                              \
+    do {                                                                             \
+        const int4 it__ = *(const int4*)(items + 4 * (w_));                          \
+        id_ = __builtin_amdgcn_readfirstlane(it__.x);                                \
+        k0_ = __builtin_amdgcn_readfirstlane(it__.y);                                \
+        k1_ = __builtin_amdgcn_readfirstlane(it__.z);                                \
+    } while (0)
 
     const int srow = lane >> 3;
     const int slot = (lane & 7) ^ srow;
 
     // ---------------- loader state (one K-tile ahead of the MFMA stream, across output tiles) ----------------
     constexpr int NTAP = MODE == EW_A_CONV3X3 ? 9 : (MODE == EW_A_CONVT3 ? 3 : 1);
-    int ld_i = 0, ld_kt = 0, ld_tap = 0, ld_cc = 0;
+    int ld_w = 0, ld_kt = 0, ld_k1 = 0, ld_tap = 0, ld_cc = 0;   // ld_kt == ld_k1: the next stage_begin opens work item ld_w
     int a_ctr[GA];                         // centre-tap pixel (row) index in the source tensors
     int a_mask[GA];                        // bits 0..8 tap validity, bits 16..27 upsample (dy,dx) codes
     const f16* b_ptr0 = p.w;               // W row of this lane's first piece (+ its 16-byte slot); piece j adds j*NW*8 rows
 
-    auto loader_new_tile = [&]() __attribute__((always_inline)) {
-        const int id = ld_i * G + seq0;
+    auto loader_new_tile = [&](const int id) __attribute__((always_inline)) {
         int tm, tn;
         tile_coords(id, p.tiles_m, p.tiles_n, p.band, tm, tn);
         const int m0 = tm * BM, n0 = tn * BN;
@@ -153,7 +188,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
         if constexpr (DIRECT)
             wrow = (wave >> 2) * 32 + ((wave >> 1) & 1) * 4 + (2 * (wave & 1) + (srow_o >> 2)) * 8 + (srow_o & 3);
         b_ptr0 = p.w + (size_t)(n0 + wrow) * p.K + slot_o * 8;                        // N % 320 == 0: every W row exists
-        ld_kt = 0; ld_tap = 0; ld_cc = 0;
     };
 
     // staging of one K-tile = stage_begin (wave-uniform source selection, advances the stream counters) + NP DMA pieces
@@ -164,7 +198,16 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
     size_t st_koff = 0;
     char* st_buf = smem;
     auto stage_begin = [&](char* buf) __attribute__((always_inline)) {
-        if (ld_kt == 0) loader_new_tile();
+        if (ld_kt == ld_k1) {
+            int id, k0;
+            EW3_GET_ITEM(ld_w, id, k0, ld_k1);
+            ++ld_w;
+            loader_new_tile(id);
+            ld_kt = k0;
+            const int chunk = k0 / NTAP;                                   // K order: channel chunk major, tap minor
+            ld_tap = k0 - chunk * NTAP;
+            ld_cc = chunk * BK;
+        }
         st_buf = buf;
         st_tap = ld_tap;
         const int cc = ld_cc;
@@ -179,7 +222,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
         st_koff = (size_t)ld_kt * BK;
         // K order: channel-chunk major, tap minor (the taps of a 64-channel chunk re-hit the same lines in L2 / TCP)
         if (++ld_tap == NTAP) { ld_tap = 0; ld_cc += BK; }
-        if (++ld_kt == nk) { ld_kt = 0; ++ld_i; }
+        ++ld_kt;
     };
     auto stage_piece = [&](int k) __attribute__((always_inline)) {     // k is a compile-time constant after unrolling
         if (k < GA) {
@@ -238,12 +281,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
 #pragma unroll
     for (int j = 0; j < PD; ++j) bfr[j] = EW3_LDS(smem + b_rd[0] + j * 2048);
 
-    int cur_i = 0, cur_kt = 0;
+    int cur_w = 0, cur_id, cur_kt, cur_k1;
+    EW3_GET_ITEM(0, cur_id, cur_kt, cur_k1);
+    cur_w = 1;
+    bool cur_tail = cur_kt > 0;                      // stream-K: this item is the tail of a tile another block finishes
     int s_cur = 0;                                   // ring slot of stream position v
     for (int v = 0; v < V; ++v) {
         const char* cur = smem + s_cur * STAGE;
         char* nxt = smem + (s_cur ^ 1) * STAGE;
-        const bool tile_end = cur_kt == nk - 1;
+        const bool tile_end = cur_kt == cur_k1 - 1;
         const bool pend = staged < V;                // K-tile v+1 exists: stage it into the other slot during steps 0..8
         if (pend) { stage_begin(nxt); ++staged; }
 #pragma unroll
@@ -290,11 +336,16 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
             }
         }
         s_cur ^= 1;
-        if (++cur_kt == nk) {
-            // ------------------------- epilogue of output tile cur_i -------------------------
-            cur_kt = 0;
-            const int id = cur_i * G + seq0;
-            ++cur_i;
+        if (++cur_kt == cur_k1) {
+            // ------------------------- end of work item: epilogue of output tile cur_id (or stream-K hand-over) -------------------------
+            const int id = cur_id;
+            const bool sk_contribute = cur_tail;             // tail of a tile: hand the partial accumulators over, no epilogue
+            const bool sk_finish = cur_k1 < nk;              // head of a tile: add the other block's partial, then the epilogue
+            if (cur_w < n_sk + n_dp) {
+                EW3_GET_ITEM(cur_w, cur_id, cur_kt, cur_k1);
+                cur_tail = cur_kt > 0;                       // never true past item 0; kept general
+            }
+            ++cur_w;
             int tm, tn;
             tile_coords(id, p.tiles_m, p.tiles_n, p.band, tm, tn);
             const bool full = (tm * BM + wm * WM + WM <= p.M);          // N is always full (N % 320 == 0)
@@ -355,7 +406,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                                 x *= p.c_acc;
                                 const f16x4 o4 = {(f16)x[0], (f16)x[1], (f16)x[2], (f16)x[3]};
                                 *(f16x4*)(patch16 + frow * LDH + jj * 16 + fks * 4) = o4;
-                                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                             }
                             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -410,7 +460,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
 #pragma unroll
                             for (int jj = 0; jj < CP / 16; ++jj) {
                                 *(f32x4*)(patch + frow * LDP + jj * 16 + fks * 4) = acc[i][h * (CP / 16) + jj];
-                                acc[i][h * (CP / 16) + jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
                             }
                             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -488,8 +537,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                         for (int q = 0; q < NQ; ++q) {
                             const int m = m_w0 + i * 16 + frow, n = ncol0 + q * 32;
                             const f32x4 a0 = acc[i][2 * q], a1 = acc[i][2 * q + 1];
-                            acc[i][2 * q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            acc[i][2 * q + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
                             float vv[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                             f16x8 o;
                             u32x2 ol;
@@ -552,8 +599,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
 #endif
                             const f16x4 o4 = {(f16)o01[0], (f16)o01[1], (f16)o23[0], (f16)o23[1]};
                             *(f16x4*)((f16*)patch + frow * (CP + 8) + q * 16 + fks * 4) = o4;      // fp16 patch, row stride 176 B
-                            acc[i][2 * q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            acc[i][2 * q + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
                         }
                         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -571,11 +616,62 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                     }
                 }
             };
+            if (sk_finish) {
+                // stream-K finisher: block seq0+1 wrote its partial of this tile as the first thing it did
+                if (tid == 0) {
+                    const unsigned* fl = sk.flags + seq0 + 1;
+                    int spins = 0;
+                    while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > (1 << 24)) {             // ~10 s: never hang the device; poison the flag word so the host sees it
+                            __hip_atomic_store(sk.flags + 1024, 0xdeadu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+                EW3_FENCE();
+                __builtin_amdgcn_s_barrier();
+                EW3_FENCE();
+                int tid_o = tid;
+                asm volatile("" : "+v"(tid_o));
+                const f32x4* wsp = (const f32x4*)sk.ws + (size_t)(seq0 + 1) * (FM * FN * 64 * NW) + tid_o;
+                // ten fragments (one accumulator row) in flight at a time: the fragment registers of the main loop are dead here,
+                // all 40 loads at once would need 160 more VGPRs than exist, two at a time was 20 serial round trips to memory
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    f32x4 t[FN];
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) t[j] = wsp[(i * FN + j) * (64 * NW)];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] += t[j];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             if (p.dbg & 2) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) { asm volatile("" :: "v"(acc[i][j])); acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                    for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(acc[i][j]));
+            } else if (sk_contribute) {
+                // stream-K contributor: accumulators -> slot seq0 of the uncached workspace in [fragment][thread] order (16 B per
+                // lane, 1 KB per wave instruction), then publish.  Every thread drains its own stores (vmcnt counts stores on
+                // gfx9) before the barrier; one thread raises the flag after it.
+                int tid_o = tid;                              // opaque copy: keeps the workspace address out of the main loop's live set
+                asm volatile("" : "+v"(tid_o));
+                f32x4* wsp = (f32x4*)sk.ws + (size_t)seq0 * (FM * FN * 64 * NW) + tid_o;
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        wsp[(i * FN + j) * (64 * NW)] = acc[i][j];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                EW3_WAIT_VM0();
+                EW3_FENCE();
+                __builtin_amdgcn_s_barrier();
+                EW3_FENCE();
+                if (tid == 0) __hip_atomic_store(sk.flags + seq0, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 if (full) epilogue(std::true_type{}); else epilogue(std::false_type{});
                 // the patch lives in the slot the next position's DMA will overwrite
@@ -584,6 +680,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
                 __builtin_amdgcn_s_barrier();
                 EW3_FENCE();
             }
+            // Every path above only READS the accumulators; they are cleared here, once, for the next work item (clearing them
+            // inside each path gave the allocator a three-way merge of 160 registers: copies and ~280 spilled VGPRs).
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             // first fragments of the next tile's first K-tile (skipped at steps 18-19 of this position)
             {
                 const char* c2 = smem + s_cur * STAGE;
@@ -596,13 +698,53 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p) {
     }
 }
 
+// ---- stream-K workspace: one per (device, stream) -- launches on one stream are ordered, so consecutive GEMMs may share it ----
+struct SkWorkspace { int dev; hipStream_t stream; float* ws; unsigned* flags; unsigned epoch; };
+constexpr int SK_SLOTS = 256;
+constexpr size_t SK_SLOT_FLOATS = (size_t)FM * FN * 4 * 64 * NW;          // 160 accumulators x 512 threads = 320 KB
+static SkWorkspace sk_pool[8];
+static int sk_pool_used = 0;
+SkWorkspace* sk_pool_entry(int i) { return i < sk_pool_used ? &sk_pool[i] : nullptr; }
+SkWorkspace* sk_workspace(hipStream_t stream) {
+    SkWorkspace* const pool = sk_pool;
+    int& used = sk_pool_used;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    for (int i = 0; i < used; ++i)
+        if (pool[i].dev == dev && pool[i].stream == stream) return &pool[i];
+    if (used == 8) return nullptr;                                          // more streams than slots: those launches run without the tail split
+    SkWorkspace w{dev, stream, nullptr, nullptr, 0};
+    // uncached (MTYPE UC) device memory: partials and flags cross XCDs inside one kernel, and the per-XCD L2s are only coherent
+    // at kernel boundaries for ordinary allocations
+    if (hipExtMallocWithFlags((void**)&w.ws, SK_SLOTS * SK_SLOT_FLOATS * sizeof(float), hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipExtMallocWithFlags((void**)&w.flags, 2048 * sizeof(unsigned), hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(w.ws); return nullptr; }
+    if (hipMemsetAsync(w.flags, 0, 2048 * sizeof(unsigned), stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    pool[used] = w;
+    return &pool[used++];
+}
+
+}  // namespace
+// 0 = every stream-K hand-over so far completed; 1 = a finisher gave up waiting (results of that launch are wrong).  Synchronises.
+extern "C" int ew_gemm_streamk_status(void) {
+    int bad = 0;
+    for (int i = 0; i < 8; ++i) {
+        SkWorkspace* w = sk_pool_entry(i);
+        if (!w) break;
+        unsigned word = 0;
+        if (hipMemcpy(&word, w->flags + 1024, sizeof(word), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        if (word) bad = 1;
+    }
+    return bad;
+}
+namespace {
+
 template <int MODE, int EPI>
 ew_status launch3(const GemmP& p, hipStream_t s) {
     GemmP q = p;
     q.tiles_m = ew_cdiv(p.M, BM);
     q.tiles_n = p.N / BN;
     q.band = ((long long)p.N * p.K * 2 > 3LL * 1024 * 1024) ? 4 : 0;
-    const size_t lds = 2 * STAGE;
+    const size_t lds = 2 * STAGE + ITEMS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<MODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -612,8 +754,30 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
     const long long tiles = (long long)q.tiles_m * q.tiles_n;
     int grid = 256;                                   // persistent: one 8-wave workgroup per CU
     if (tiles < grid) grid = (int)((tiles + 7) / 8 * 8);
+    // Stream-K tail: T tiles over 256 blocks cost ceil(T/256) rounds; every C-wide output of the U-Net is 1800 / 900 / 452 tiles =
+    // 7.03 / 3.52 / 1.77 rounds paid as 8 / 4 / 2.  When the loss is worth it, the last (T mod 256) + 256 tiles are cut along K
+    // into 256 equal ranges instead (gemm3_kernel: contributor / finisher hand-over through the uncached workspace).
+    SkP sk{nullptr, nullptr, 0u, 0, 0};
+    static const int sk_mode = getenv("EW_G3_SK") ? atoi(getenv("EW_G3_SK")) : 1;          // 0 = off (A/B), 1 = on, 2 = every shape
+    static const int sk_min_k = getenv("EW_G3_SK_MINK") ? atoi(getenv("EW_G3_SK_MINK")) : 1280;
+    // Where it pays (A/B per shape on the U-Net's problems, same box): 3x3 convs at every level (-6 ... -10 %), dense / temporal
+    // GEMMs with at most two tile columns and K >= 1280 (-4 ... -8 %).  With four tile columns (level 2) the blocks of an XCD
+    // are out of phase along K and stop sharing the A rows and W slices in L2: +7 ... +16 % -- left on the whole-tile schedule.
+    const bool sk_shape = MODE == EW_A_CONV3X3 || (q.tiles_n <= 2 && p.K >= sk_min_k) || sk_mode == 2;
+    if (sk_mode && sk_shape && !(p.dbg & 4) && grid == 256 && tiles > 256 && tiles % 256 != 0) {
+        const long long rounds = (tiles + 255) / 256;
+        const double loss = 1.0 - (double)tiles / (256.0 * rounds);
+        if (loss > 0.04) {
+            SkWorkspace* w = sk_workspace(s);
+            if (w) {
+                sk.dp_rounds = (int)(tiles / 256) - 1;
+                sk.tiles = (int)(tiles - 256LL * sk.dp_rounds);
+                sk.ws = w->ws; sk.flags = w->flags; sk.epoch = ++w->epoch;
+            }
+        }
+    }
     snprintf(g_gemm_last_kernel, 64, "gemm3_kernel<%d, %d>", MODE, EPI);
-    hipLaunchKernelGGL((gemm3_kernel<MODE, EPI>), dim3(grid), dim3(64 * NW), lds, s, q);
+    hipLaunchKernelGGL((gemm3_kernel<MODE, EPI>), dim3(grid), dim3(64 * NW), lds, s, q, sk);
     return ew_check_launch("ew_gemm_f16(gen3)");
 }
 
@@ -650,6 +814,7 @@ ew_status dispatch_epi3(const GemmP& p, hipStream_t s) {
 // true when generation 3 can run the problem AND is expected to be the faster choice (enough 256x320 tiles to fill the chip)
 bool ew_gemm3_wants(const GemmP& p) {
     if (p.N % BN != 0 || p.M < 4 * BM) return false;
+    if ((long long)ew_cdiv(p.M, BM) * (p.N / BN) > 256LL * (ITEMS_BYTES / 16 - 4)) return false;     // work-item table of a persistent block
     // GELU (CLIP's fc1) is only compiled into the plain dense variant: the erf code in every epilogue cost the conv variants
     // 11-28 spilled VGPRs (reloads inside the K loop, 4-10 % slower); anything else with GELU runs on generation 2
     if (p.act == EW_ACT_GELU && (p.mode != EW_A_DENSE || p.rowbias || p.r1 || p.r2 || p.out_lo)) return false;

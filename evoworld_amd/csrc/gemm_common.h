@@ -27,6 +27,17 @@ struct GemmP {
     int dbg;   // experiment switches (tools/bench_kernels.py): bit0 skip output stores, bit1 skip epilogue entirely
 };
 
+// generation 3, stream-K tail (gemm3_f16.hip), passed as a second kernel argument (GemmP is kept under 256 bytes: beyond that the
+// by-value kernel argument was copied to scratch instead of being read from the kernarg segment): the last `tiles` (G <= tiles <
+// 2G) output tiles are split along K over the G persistent blocks; 0 = off.  ws: uncached fp32 partial-accumulator slots, flags:
+// one word per slot, epoch: the value a slot's flag takes when its partial of THIS launch is complete.
+struct SkP {
+    float* ws;
+    unsigned* flags;
+    unsigned epoch;
+    int tiles, dp_rounds;
+};
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 

@@ -154,3 +154,60 @@ def test_conv_temporal(ops, lib):
     assert rel_l2(g3.float().cpu(), y.cpu()) < 1e-3
     assert rel_l2(g3.float().cpu(), g1.float().cpu()) < 1e-3
 
+
+
+# ----------------------------------------------------------------------------- stream-K tail
+@pytest.mark.parametrize("case", ["dense_res", "conv", "convt", "dense_k320"])
+def test_streamk_tail_matches_whole_tile_schedule(case):
+    """Generation 3 splits the last round of tiles along K (stream-K tail) when whole-tile rounds would idle > 4 % of the chip.
+    Same problem with the split switched off (ew_set_gemm_debug bit 2): results may differ only by the fp32 summation order of the
+    split tiles, i.e. by rare 1-ulp flips of the fp16 outputs; the split itself is deterministic (two runs bit-identical)."""
+    from evoworld_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    rnd = lambda *s: (torch.rand(*s, generator=g) * 2 - 1)
+    if case == "dense_res":                  # level-1 feed-forward down projection: 900 tiles = 3.52 rounds
+        M, N, K = 115200, 640, 2560
+        x, w, b = rnd(M, K).half().to(DEV), (rnd(N, K) / 32).half().to(DEV), rnd(N).half().to(DEV)
+        r1 = ops.Res.from_float(rnd(M, N).to(DEV) * 3)
+        run = lambda out: ops.gemm(x, w, out, M=M, N=N, c1=K, lda=K, bias=b, r1=r1, ld_r1=N)
+        mk = lambda: ops.Res.empty(M, N, DEV, True)
+    elif case == "dense_k320":               # K below the default threshold: must take the whole-tile schedule either way
+        M, N, K = 115200, 640, 320
+        x, w, b = rnd(M, K).half().to(DEV), (rnd(N, K) / 16).half().to(DEV), rnd(N).half().to(DEV)
+        run = lambda out: ops.gemm(x, w, out, M=M, N=N, c1=K, lda=K, bias=b)
+        mk = lambda: torch.empty(M, N, dtype=torch.float16, device=DEV)
+    elif case == "conv":                     # level-0 3x3 conv + row-bias: 1800 tiles = 7.03 rounds, K = 2880 (45 K-tiles, taps inside)
+        n, C, H, W = 50, 320, 72, 128
+        M = n * H * W
+        x, w, b = rnd(M, C).half().to(DEV), (rnd(C, 9 * C) / 40).half().to(DEV), rnd(C).half().to(DEV)
+        rb = rnd(n, C).half().to(DEV)
+        run = lambda out: ops.gemm(x, w, out, M=M, N=C, c1=C, lda=C, bias=b, mode=ops.A_CONV3X3, conv=(n, H, W, H, W, 1, 0),
+                                   rowbias=rb, rows_per_group=H * W, ld_rowbias=C)
+        mk = lambda: torch.empty(M, C, dtype=torch.float16, device=DEV)
+    else:                                    # level-1 temporal conv (3 taps) with a split residual
+        B, T, P, C = 2, 25, 2304, 640
+        M = B * T * P
+        x, w, b = rnd(M, C).half().to(DEV), (rnd(C, 3 * C) / 30).half().to(DEV), rnd(C).half().to(DEV)
+        r1 = ops.Res.from_float(rnd(M, C).to(DEV))
+        run = lambda out: ops.gemm(x, w, out, M=M, N=C, c1=C, lda=C, bias=b, mode=ops.A_CONVT3, tconv=(B, T, P), r1=r1, ld_r1=C)
+        mk = lambda: ops.Res.empty(M, C, DEV, True)
+    fl = lambda o: o.float() if isinstance(o, ops.Res) else o.float()
+    outs = []
+    for dbg in (0, 0, 4):
+        lib.ew_set_gemm_debug(dbg)
+        try:
+            o = mk()
+            run(o)
+            torch.cuda.synchronize()
+            outs.append(o)
+        finally:
+            lib.ew_set_gemm_debug(0)
+    assert lib.ew_gemm_streamk_status() == 0
+    a, b2, c = (fl(o) for o in outs)
+    assert torch.equal(a, b2)                                    # deterministic
+    err = rel_l2(a.cpu(), c.cpu())
+    print(f"stream-K {case}: rel-L2 vs whole-tile schedule {err:.2e}, max abs {float((a - c).abs().max()):.3e}")
+    assert err < 2e-5
+    if case == "dense_k320":
+        assert torch.equal(a, c)
