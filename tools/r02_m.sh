@@ -1,0 +1,6 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02m; mkdir -p $O
+for s in 0 1 0 1; do
+EW_G3_SHORT=$s timeout 900 python bench.py --steps 1 --warmup 1 --denoise-steps 6 --no-cpu-baseline > $O/bench$s.log 2>&1
+grep '^{' $O/bench$s.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('EW_G3_SHORT=$s forward ms', d['config']['unet_forward_ms'])"
+done
