@@ -87,13 +87,17 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     // starts with the TAIL of a tile (k0 > 0: this block contributes its partial accumulators to slot seq0 -- first thing it
     // does), continues with whole tiles and ends with the HEAD of a tile (k1 < nk: this block finishes that tile with the
     // partial of block seq0+1 -- which that block wrote at its very start, so the wait is short by construction).
-    const int sk_U = sk.tiles * nk;
-    const int sk_u0 = sk.tiles ? (int)((long long)seq0 * sk_U / G) : 0;
-    const int sk_u1 = sk.tiles ? (int)((long long)(seq0 + 1) * sk_U / G) : 0;
+    // (the dense variant with row-bias + two split residuals, <0,23>, is compiled without the tail split: its epilogue is already
+    // over the register budget and the extra code doubled its spills: 4.6 -> 5.9 ms per forward)
+    constexpr bool SK_OK = !(MODE == EW_A_DENSE && EPI == 23);
+    const int sk_tiles = SK_OK ? sk.tiles : 0;
+    const int sk_U = sk_tiles * nk;
+    const int sk_u0 = sk_tiles ? (int)((long long)seq0 * sk_U / G) : 0;
+    const int sk_u1 = sk_tiles ? (int)((long long)(seq0 + 1) * sk_U / G) : 0;
     const int sk_tA = sk_u0 / nk, sk_kA = sk_u0 - sk_tA * nk, sk_tB = sk_u1 / nk, sk_kB = sk_u1 - sk_tB * nk;
-    const int n_sk = sk.tiles ? (sk_tB - sk_tA) + (sk_kB > 0 ? 1 : 0) : 0;
+    const int n_sk = sk_tiles ? (sk_tB - sk_tA) + (sk_kB > 0 ? 1 : 0) : 0;
     const int sk_id0 = sk.dp_rounds * G;
-    const int n_dp = sk.tiles ? sk.dp_rounds : (seq0 < total_tiles ? (total_tiles - 1 - seq0) / G + 1 : 0);
+    const int n_dp = sk_tiles ? sk.dp_rounds : (seq0 < total_tiles ? (total_tiles - 1 - seq0) / G + 1 : 0);
     const int V = (sk_u1 - sk_u0) + n_dp * nk;                         // K-tile stream length of this block
     if (V == 0) return;
     // The items (tile id, first K-tile, end K-tile) go into a small LDS table behind the two stages: the loader and the MFMA
@@ -339,8 +343,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
         if (++cur_kt == cur_k1) {
             // ------------------------- end of work item: epilogue of output tile cur_id (or stream-K hand-over) -------------------------
             const int id = cur_id;
-            const bool sk_contribute = cur_tail;             // tail of a tile: hand the partial accumulators over, no epilogue
-            const bool sk_finish = cur_k1 < nk;              // head of a tile: add the other block's partial, then the epilogue
+            const bool sk_contribute = SK_OK && cur_tail;             // tail of a tile: hand the partial accumulators over, no epilogue
+            const bool sk_finish = SK_OK && cur_k1 < nk;              // head of a tile: add the other block's partial, then the epilogue
             if (cur_w < n_sk + n_dp) {
                 EW3_GET_ITEM(cur_w, cur_id, cur_kt, cur_k1);
                 cur_tail = cur_kt > 0;                       // never true past item 0; kept general
@@ -632,21 +636,30 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                 EW3_FENCE();
                 __builtin_amdgcn_s_barrier();
                 EW3_FENCE();
-                int tid_o = tid;
-                asm volatile("" : "+v"(tid_o));
-                const f32x4* wsp = (const f32x4*)sk.ws + (size_t)(seq0 + 1) * (FM * FN * 64 * NW) + tid_o;
-                // ten fragments (one accumulator row) in flight at a time: the fragment registers of the main loop are dead here,
-                // all 40 loads at once would need 160 more VGPRs than exist, two at a time was 20 serial round trips to memory
+                // The partial comes in through the LDS-DMA path into the stage the K loop has just released (9 KB per wave: eight
+                // 1 KB pieces in flight, no VGPRs), then one fragment at a time is read back and added: five round trips to memory,
+                // and no register demand on top of the 160 live accumulators (ten fragments in VGPRs cost <0,23> 18 more spills).
+                int lane_o = tid & 63;
+                asm volatile("" : "+v"(lane_o));
+                const f32x4* wsp = (const f32x4*)sk.ws + (size_t)(seq0 + 1) * (FM * FN * 64 * NW) + wave * 64 + lane_o;
+                char* const stg = smem + (s_cur ^ 1) * STAGE + wave * 8192;
 #pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    f32x4 t[FN];
+                for (int b0 = 0; b0 < FM * FN; b0 += 8) {
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) t[j] = wsp[(i * FN + j) * (64 * NW)];
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int u = 0; u < 8; ++u) glds16((const f16*)(wsp + (b0 + u) * (64 * NW)), stg + u * 1024);
+                    EW3_WAIT_VM0();
+                    EW3_FENCE();
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) acc[i][j] += t[j];
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int u = 0; u < 8; ++u) {
+                        const int f = b0 + u;
+                        acc[f / FN][f % FN] += *(const f32x4*)(stg + u * 1024 + lane_o * 16);
+                    }
+                    EW3_WAIT_LGKM0();
+                    EW3_FENCE();
                 }
+                // the staging regions (8 KB per wave) overlap the other waves' epilogue patches (5.25 KB per wave) in the same stage
+                __builtin_amdgcn_s_barrier();
+                EW3_FENCE();
             }
             if (p.dbg & 2) {
 #pragma unroll
@@ -764,7 +777,7 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
     // GEMMs with at most two tile columns and K >= 1280 (-4 ... -8 %).  With four tile columns (level 2) the blocks of an XCD
     // are out of phase along K and stop sharing the A rows and W slices in L2: +7 ... +16 % -- left on the whole-tile schedule.
     const bool sk_shape = MODE == EW_A_CONV3X3 || (q.tiles_n <= 2 && p.K >= sk_min_k) || sk_mode == 2;
-    if (sk_mode && sk_shape && !(p.dbg & 4) && grid == 256 && tiles > 256 && tiles % 256 != 0) {
+    if (sk_mode && sk_shape && !(MODE == EW_A_DENSE && EPI == 23) && !(p.dbg & 4) && grid == 256 && tiles > 256 && tiles % 256 != 0) {
         const long long rounds = (tiles + 255) / 256;
         const double loss = 1.0 - (double)tiles / (256.0 * rounds);
         if (loss > 0.04) {
