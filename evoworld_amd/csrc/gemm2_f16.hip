@@ -573,7 +573,7 @@ ew_status launch2(const GemmP& p, hipStream_t s) {
     return ew_check_launch("ew_gemm_f16(gen2)");
 }
 
-// Tile / workgroup shape: 8-wave workgroups, 3-stage ring, 256x160 where N is a multiple of 160, else (and for GEGLU) 128x256.
+// Tile / workgroup shape: 8-wave workgroups, 3-stage ring, 256x160 where N is a multiple of 160 or at most 160, else (and for GEGLU) 128x256.
 // (Measured and dropped: 2 workgroups of 4 waves per CU with 128x160 / 128x128 tiles and a 2-stage ring, with and without a
 // start-phase offset; chip-wide start staggering; 4 waves x 512 VGPRs; a 256x256 / 2-stage GEGLU tile -- DESIGN.md 3.1.)
 template <int MODE, int EPI>
@@ -581,7 +581,8 @@ ew_status dispatch_tile(const GemmP& p, hipStream_t s) {
     if constexpr (EPI & 8) {
         return launch2<128, 256, 2, 4, 3, MODE, EPI>(p, s);
     } else {
-        if (p.N % 160 == 0) return launch2<256, 160, 4, 2, 3, MODE, EPI>(p, s);
+        // N <= 160 (the VAE's 128-channel convs at full resolution): one 160-wide tile column wastes 20 % of it, a 256-wide one half
+        if (p.N % 160 == 0 || p.N <= 160) return launch2<256, 160, 4, 2, 3, MODE, EPI>(p, s);
         return launch2<128, 256, 2, 4, 3, MODE, EPI>(p, s);
     }
 }
