@@ -168,6 +168,29 @@ def kernel_breakdown(unet, pipe, latents, image_latents, ehs, plucker, T, h, w, 
     return out
 
 
+def fp16_stream_forward_ms(unet, ehs, T, h, w, n=3):
+    """The same forward with the residual stream kept in plain fp16 (EW_RESIDUAL=fp16: the round-1 layout, 1.4e-3 rel-L2 against
+    the fp32 oracle instead of 8.9e-4) -- reported next to the headline so that what parity at 1e-3 costs is measured on the
+    same box in the same process.  Not part of the timed region, never the reported value."""
+    keep = (unet.split_residual, unet.split_heads)
+    unet.split_residual = unet.split_heads = False
+    try:
+        dev = ehs.device
+        x_in = torch.zeros(2 * T * h * w, 64, dtype=torch.float16, device=dev)
+        ids = torch.tensor([[6.0, 127.0, 0.02]] * 2, device=dev)
+        e2 = torch.cat([torch.zeros_like(ehs), ehs], 0).to(torch.float16)
+        unet.forward_nhwc(x_in, 1.0, e2, ids, 2, T, h, w)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n):
+            unet.forward_nhwc(x_in, 1.0, e2, ids, 2, T, h, w)
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / n
+    finally:
+        unet.split_residual, unet.split_heads = keep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -274,6 +297,7 @@ def main():
     finite = all(bool(torch.isfinite(r).all()) for r in res)
 
     kernels = kernel_breakdown(unet, pipe, latents, image_latents, ehs, plucker, T, h, w) if rank == 0 else None
+    fp16_ms = fp16_stream_forward_ms(unet, ehs, T, h, w) if rank == 0 and unet.split_residual else None
 
     if rank == 0:
         fw_ms = sum(s.elapsed_time(e) for s, e in fw_events) / max(1, len(fw_events))
@@ -287,7 +311,8 @@ def main():
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"configs[1]: single clip {args.height}x{args.width}x{T}f, {args.denoise_steps} EulerDiscrete "
                                    "steps, CFG batch 2, random-init SVD-Xtend U-Net (in_channels 18), one clip per GPU",
-                       "unet_forward_ms": fw_ms, "valid": bool(full and finite)},
+                       "unet_forward_ms": fw_ms, "residual_stream": "split fp16 + int8 (3 B/elt)" if unet.split_residual else "fp16",
+                       "unet_forward_ms_fp16_stream": fp16_ms, "valid": bool(full and finite)},
             "roofline": {"bound": "mfma", "kernel": "U-Net denoise step (all launches of one forward, HIP events on the launch stream)",
                          "achieved": ach, "peak": PEAK_F16_DENSE_TFLOPS, "unit": "TFLOP/s",
                          "frac": (ach / PEAK_F16_DENSE_TFLOPS) if ach else None,

@@ -16,6 +16,7 @@
 // BasicTransformerBlock.attn1 and TemporalBasicTransformerBlock.attn1, instantiated through
 // evoworld/trainer/unet_plucker.py:13,161-233.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -71,8 +72,18 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         vr0 = c < S ? *(const f16x8*)(vbase + key0) : z;
         vr1 = c + 8 < S ? *(const f16x8*)(vbase + key0 + 8) : z;
     };
-    auto write_tile = [&](int buf) {
-        char* const kl = smem + buf * 16384;
+    // Full tiles (all but a ragged last one) load through per-lane pointers advanced by one tile per iteration: the generic
+    // form above costs a 64-bit multiply-add and two clamps per tile and lane, and this loop is VALU-bound.
+    const f16* kp_run = kbase + (tok0 + srow) * ld_qk;      // tile 0 (only dereferenced for tiles that lie completely below S)
+    const f16* vp_run = vbase;
+    auto load_tile_full = [&]() __attribute__((always_inline)) {
+        kr0 = *(const f16x8*)kp_run;
+        kr1 = *(const f16x8*)(kp_run + 8);
+        vr0 = *(const f16x8*)vp_run;
+        vr1 = *(const f16x8*)(vp_run + 8);
+    };
+    auto write_tile = [&](auto buf_tag) __attribute__((always_inline)) {
+        char* const kl = smem + decltype(buf_tag)::value * 16384;     // compile-time buffer: the offset folds into the ds_write
         char* const vl = kl + 8192;
         *(f16x8*)(kl + k_w0) = kr0;
         *(f16x8*)(kl + k_w1) = kr1;
@@ -100,13 +111,21 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     constexpr float DEFER_THR = 6.0f;   // log2 units: the running max is raised only when a tile exceeds it by 2^6 (T13)
     const int nt = (S + 63) / 64;
     load_tile(0);
-    write_tile(0);
+    write_tile(std::integral_constant<int, 0>{});
     __syncthreads();
-    for (int j = 0; j < nt; ++j) {
+    // One 64-key tile; the LDS buffer it reads (BUF) and the one it refills (BUF ^ 1) are compile-time constants: the loop is
+    // unrolled by two below, so buffer selection costs no VALU (it used to be eight xors on the fragment offsets plus address
+    // arithmetic on the four tile stores per iteration).
+    auto tile_step = [&](const int j, auto buf_tag) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_tag)::value;
         const int key0 = j * 64;
-        const char* kb = kl;                         // the buffer toggle lives in foff (bit 14), see the end of the loop
-        const char* vb = vl;
-        if (j + 1 < nt) load_tile(key0 + 64);
+        const char* kb = kl + BUF * 16384;
+        const char* vb = vl + BUF * 16384;
+        if (j + 1 < nt) {
+            kp_run += (long long)64 * ld_qk;
+            vp_run += 64;
+            if (key0 + 128 <= S) load_tile_full(); else load_tile(key0 + 64);
+        }
 
         // ---- S^T = K Q^T : two 32-key blocks ----
         f32x16 sacc[2];
@@ -182,13 +201,15 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
             }
         }
         // double-buffered tiles: the other buffer was last read in iteration j-1 (every wave passed that barrier)
-        if (j + 1 < nt) write_tile((j + 1) & 1);
-#pragma unroll
-        for (int bq = 0; bq < 2; ++bq)
-#pragma unroll
-            for (int sq = 0; sq < 4; ++sq) foff[bq][sq] ^= 16384;   // next tile sits in the other buffer
+        if (j + 1 < nt) write_tile(std::integral_constant<int, BUF ^ 1>{});
         __syncthreads();
+    };
+    int j = 0;
+    for (; j + 1 < nt; j += 2) {
+        tile_step(j, std::integral_constant<int, 0>{});
+        tile_step(j + 1, std::integral_constant<int, 1>{});
     }
+    if (j < nt) tile_step(j, std::integral_constant<int, 0>{});
     // ---- normalise + store: lane holds query q_idx, d = 32*db + 8*(r>>2) + 4*lh + (r&3) ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
