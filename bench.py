@@ -201,6 +201,7 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--denoise-steps", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp16-stream", action="store_true", help="skip the extra fp16-stream forwards (profiling runs: keeps the launch count at steps x denoise-steps + 1)")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="time ONE complete full-size CPU forward (minutes) instead of the bounded sample")
     ap.add_argument("--tiny", action="store_true", help="shrunken U-Net (plumbing check only; result flagged invalid)")
     args = ap.parse_args()
@@ -297,7 +298,7 @@ def main():
     finite = all(bool(torch.isfinite(r).all()) for r in res)
 
     kernels = kernel_breakdown(unet, pipe, latents, image_latents, ehs, plucker, T, h, w) if rank == 0 else None
-    fp16_ms = fp16_stream_forward_ms(unet, ehs, T, h, w) if rank == 0 and unet.split_residual else None
+    fp16_ms = fp16_stream_forward_ms(unet, ehs, T, h, w) if rank == 0 and unet.split_residual and not args.no_fp16_stream else None
 
     if rank == 0:
         fw_ms = sum(s.elapsed_time(e) for s, e in fw_events) / max(1, len(fw_events))

@@ -11,7 +11,7 @@ mkdir -p $REPO/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_t
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_t -o p -- python $REPO/bench.py --steps 1 --warmup 0 --denoise-steps 1 --no-cpu-baseline > /tmp/pmc_t.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_t -o p -- python $REPO/bench.py --steps 1 --warmup 0 --denoise-steps 1 --no-cpu-baseline --no-fp16-stream > /tmp/pmc_t.log 2>&1
   python - $c $REPO <<'PY'
 import csv, glob, collections, sys, json, os
 c, repo = sys.argv[1], sys.argv[2]
@@ -41,11 +41,11 @@ w = json.load(open(os.path.join(repo, "gpurun_out", "r02_hbm_traffic_WRITE_SIZE.
 forwards = 2
 read_b = f["raw_total_kb"] * 1024 * 2.0 / forwards      # gfx950: FETCH_SIZE counts 64 B per 128-B request
 write_b = w["raw_total_kb"] * 1024 * 1.0 / forwards
-# calibration on ln_kernel<1,4>: 25 launches per forward on 460800 x 320 rows: read hi + lo (2 x 2 B), write 2 B per element
+# calibration on ln_kernel<1,4>: 25 launches per forward on 460800 x 320 rows: read hi (2 B) + lo8 (1 B), write 2 B per element
 ln_elems = 460800 * 320
 cal = {}
 if f["ln_kernel_1_4"]:
-    n = f["ln_kernel_1_4"][0]["launches"]; cal["fetch_factor_measured"] = n * ln_elems * 4 / (f["ln_kernel_1_4"][0]["raw_kb"] * 1024)
+    n = f["ln_kernel_1_4"][0]["launches"]; cal["fetch_factor_measured"] = n * ln_elems * 3 / (f["ln_kernel_1_4"][0]["raw_kb"] * 1024)
 if w["ln_kernel_1_4"]:
     n = w["ln_kernel_1_4"][0]["launches"]; cal["write_factor_measured"] = n * ln_elems * 2 / (w["ln_kernel_1_4"][0]["raw_kb"] * 1024)
 out = {"bytes_per_forward": read_b + write_b, "read_bytes_per_forward": read_b, "written_bytes_per_forward": write_b,
