@@ -1,5 +1,5 @@
 #!/bin/bash
-# current build: default bench (with breakdown) + by-shape breakdown + rocprofv3 kernel stats of a short run.  Usage: tools/r02_g.sh <tag>
+# current build: default bench (with breakdown) + by-shape breakdown + rocprofv3 kernel stats of a short run.  Usage: tools/profile_forward.sh <tag>
 TAG=${1:-g}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02$TAG
