@@ -31,8 +31,22 @@ namespace {
 #define EW3_LDS(ptr) (*(const f16x8*)(ptr))
 #endif
 
-constexpr int BM = 256, BN = 320, BK = 64, NW = 8, WAVES_N = 2;
-constexpr int WM = 64, WN = 160, FM = 4, FN = 10;
+// The file is compiled twice (Makefile): EW3_BN = 320 (every channel count of the U-Net) and EW3_BN = 256 (gemm3b_f16.o: the VAE's
+// 256- / 512-channel convs, which otherwise run on generation 2's 128x256 tile at about a third of this kernel's rate).
+#ifndef EW3_BN
+#define EW3_BN 320
+#endif
+#if EW3_BN == 320
+#define EW3_NAME(x) x
+#define EW3_KERNEL_STR "gemm3_kernel"
+#else
+#define EW3_NAME(x) x##_b256
+#define EW3_KERNEL_STR "gemm3b_kernel"
+#define gemm3_kernel gemm3b_kernel
+#endif
+constexpr int BM = 256, BN = EW3_BN, BK = 64, NW = 8, WAVES_N = 2;
+constexpr int WM = 64, WN = BN / WAVES_N, FM = 4, FN = WN / 16;
+static_assert(BN % 64 == 0 && FN % 2 == 0 && (FM * FN) % 8 == 0, "tile geometry");
 constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
 constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW, NP = GA + GB;        // 4 + 5 DMA pieces per wave per K-tile
 constexpr int NSTEP = 2 * FN;                                          // 20 steps (k-half, W fragment) per K-tile
@@ -355,7 +369,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
             const bool full = (tm * BM + wm * WM + WM <= p.M);          // N is always full (N % 320 == 0)
             // wave-private fp32 patch in the slot just consumed (free since the barrier of step 17; the DMA of the next
             // K-tile into it is issued by the NEXT position, after the closing barrier below)
-            constexpr int CP = 80;                                 // columns per pass
+            constexpr int CP = WN / 2;                             // columns per pass (80 at BN = 320)
             constexpr int LDP = CP + 4;                            // patch row stride (floats)
             float* patch = (float*)(smem + (s_cur ^ 1) * STAGE) + wave * (16 * LDP);
             const int m_w0 = tm * BM + wm * WM, n_w0 = tn * BN + wn * WN;
@@ -738,8 +752,16 @@ SkWorkspace* sk_workspace(hipStream_t stream) {
 
 }  // namespace
 // 0 = every stream-K hand-over so far completed; 1 = a finisher gave up waiting (results of that launch are wrong).  Synchronises.
+#if EW3_BN == 320
+int ew_gemm3_sk_status_b256();
 extern "C" int ew_gemm_streamk_status(void) {
+    const int other = ew_gemm3_sk_status_b256();
+    if (other < 0) return other;
+    int bad = other;
+#else
+int ew_gemm3_sk_status_b256() {
     int bad = 0;
+#endif
     for (int i = 0; i < 8; ++i) {
         SkWorkspace* w = sk_pool_entry(i);
         if (!w) break;
@@ -789,7 +811,7 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
             }
         }
     }
-    snprintf(g_gemm_last_kernel, 64, "gemm3_kernel<%d, %d>", MODE, EPI);
+    snprintf(g_gemm_last_kernel, 64, EW3_KERNEL_STR "<%d, %d>", MODE, EPI);
     hipLaunchKernelGGL((gemm3_kernel<MODE, EPI>), dim3(grid), dim3(64 * NW), lds, s, q, sk);
     return ew_check_launch("ew_gemm_f16(gen3)");
 }
@@ -825,8 +847,9 @@ ew_status dispatch_epi3(const GemmP& p, hipStream_t s) {
 }  // namespace
 
 // true when generation 3 can run the problem AND is expected to be the faster choice (enough 256x320 tiles to fill the chip)
-bool ew_gemm3_wants(const GemmP& p) {
+bool EW3_NAME(ew_gemm3_wants)(const GemmP& p) {
     if (p.N % BN != 0 || p.M < 4 * BM) return false;
+    if (BN != 320 && p.N % 320 == 0) return false;                      // the 320-wide instance takes what it can
     if ((long long)ew_cdiv(p.M, BM) * (p.N / BN) > 256LL * (ITEMS_BYTES / 16 - 4)) return false;     // work-item table of a persistent block
     // GELU (CLIP's fc1) is only compiled into the plain dense variant: the erf code in every epilogue cost the conv variants
     // 11-28 spilled VGPRs (reloads inside the K loop, 4-10 % slower); anything else with GELU runs on generation 2
@@ -843,7 +866,7 @@ bool ew_gemm3_wants(const GemmP& p) {
     return tiles >= 200;
 }
 
-ew_status ew_gemm3_dispatch(const GemmP& p, hipStream_t s) {
+ew_status EW3_NAME(ew_gemm3_dispatch)(const GemmP& p, hipStream_t s) {
     if (p.mode == EW_A_CONV3X3) return dispatch_epi3<EW_A_CONV3X3>(p, s);
     if (p.mode == EW_A_CONVT3) return dispatch_epi3<EW_A_CONVT3>(p, s);
     return dispatch_epi3<EW_A_DENSE>(p, s);

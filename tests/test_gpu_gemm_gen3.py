@@ -211,3 +211,92 @@ def test_streamk_tail_matches_whole_tile_schedule(case):
     assert err < 2e-5
     if case == "dense_k320":
         assert torch.equal(a, c)
+
+
+# ----------------------------------------------------------------------------- the 256-wide instance (VAE channel counts)
+def _both_b(lib, fn):
+    lib.ew_set_gemm_generation(3)
+    a = fn()
+    a = a.float().clone() if hasattr(a, "float") else a
+    assert lib.ew_gemm_last_kernel().decode().startswith("gemm3b_kernel"), lib.ew_gemm_last_kernel()
+    lib.ew_set_gemm_generation(2)
+    b = fn()
+    b = b.float().clone()
+    assert lib.ew_gemm_last_kernel().decode().startswith("gemm2_kernel")
+    lib.ew_set_gemm_generation(3)
+    return a, b
+
+
+@pytest.mark.parametrize("M,N,K,eps", [(61237, 256, 320, "bias"), (52011, 512, 192, "rb+r1"), (70000, 256, 1920, "r1+r2"),
+                                        (51456, 512, 64, "silu"), (26000, 1024, 448, "split"), (140000, 256, 2304, "split")])
+def test_b256_dense_epilogues(ops, lib, M, N, K, eps):
+    """gemm3_f16.hip compiled with EW3_BN = 256 (N % 256 == 0 and N % 320 != 0): every epilogue family against fp32 torch and
+    against generation 2, incl. the split residual stream and (last case: 547 x 1 tiles, K = 2304) the stream-K tail."""
+    x, w, b = rnd(M, K, seed=1).half().to(DEV), (rnd(N, K, seed=2) / math.sqrt(K)).half().to(DEV), rnd(N, seed=3).half().to(DEV)
+    rpg = 7001
+    G = M // rpg + 1
+    rb = rnd(G, N + 64, seed=4).half().to(DEV) if "rb" in eps else None
+    split = eps == "split"
+    r1f = rnd(M, N, seed=5).to(DEV)
+    r1 = (ops.Res.from_float(r1f) if split else r1f.half()) if ("r1" in eps or split) else None
+    r2 = rnd(M, N + 8, seed=6).half().to(DEV) if "r2" in eps else None
+    act = ops.ACT_SILU if eps == "silu" else ops.ACT_NONE
+
+    def run():
+        out = ops.Res.empty(M, N, DEV, True) if split else torch.empty(M, N, dtype=torch.float16, device=DEV)
+        ops.gemm(x, w, out, M=M, N=N, c1=K, lda=K, bias=b, rowbias=None if rb is None else rb[:, 64:], ld_rowbias=N + 64,
+                 rows_per_group=rpg, r1=r1, ld_r1=N, r2=r2, ld_r2=N + 8, act=act, c_acc=0.7, c_r1=0.6, c_r2=-1.5)
+        return out
+    g3, g2 = _both_b(lib, run)
+    y = x.float() @ w.float().T + b.float()
+    if rb is not None:
+        y = y + rb[:, 64:].float()[torch.arange(M, device=DEV) // rpg]
+    if act:
+        y = F.silu(y)
+    y = 0.7 * y
+    if r1 is not None:
+        y = y + 0.6 * r1.float()
+    if r2 is not None:
+        y = y - 1.5 * r2[:, :N].float()
+    tol = 2e-5 if split else 1e-3
+    assert rel_l2(g3.cpu(), y.cpu()) < tol
+    assert rel_l2(g3.cpu(), g2.cpu()) < tol
+    assert lib.ew_gemm_streamk_status() == 0
+
+
+@pytest.mark.parametrize("C,O,H,W,mode", [(256, 256, 96, 128, "plain"), (512, 512, 96, 128, "res"), (512, 256, 96, 128, "up"),
+                                           (128, 256, 192, 256, "shift")])
+def test_b256_conv3x3(ops, lib, C, O, H, W, mode):
+    """VAE conv shapes on the 256-wide instance: plain, + residual, nearest-x2 upsample addressing, Downsample2D(padding=0)
+    taps (conv_shift) -- against F.conv2d in fp32 and against generation 2."""
+    n = 6
+    x = rnd(n, C, H, W, seed=1).half()
+    w = (rnd(O, C, 3, 3, seed=2) / math.sqrt(9 * C)).half()
+    b = rnd(O, seed=3).half()
+    xin = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV)
+    wp = w.permute(0, 2, 3, 1).reshape(O, 9, C // 64, 64).permute(0, 2, 1, 3).reshape(O, 9 * C).contiguous().to(DEV)   # [O, C/64, tap, 64]
+    stride, up, shift = 1, 0, 0
+    if mode == "up":
+        Ho, Wo, up = 2 * H, 2 * W, 1
+        ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1)
+    elif mode == "shift":
+        stride, shift = 2, 1
+        Ho, Wo = H // 2, W // 2
+        ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), b.float(), stride=2)
+    else:
+        Ho, Wo = H, W
+        ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
+    M = n * Ho * Wo
+    r1 = rnd(M, O, seed=4).half().to(DEV) if mode == "res" else None
+    if r1 is not None:
+        ref = ref + r1.float().cpu().reshape(n, Ho, Wo, O).permute(0, 3, 1, 2)
+
+    def run():
+        out = torch.empty(M, O, dtype=torch.float16, device=DEV)
+        ops.gemm(xin, wp, out, M=M, N=O, c1=C, lda=C, bias=b.to(DEV), mode=ops.A_CONV3X3, conv=(n, H, W, Ho, Wo, stride, up),
+                 r1=r1, ld_r1=O, conv_shift=shift)
+        return out
+    g3, g2 = _both_b(lib, run)
+    got = g3.reshape(n, Ho, Wo, O).permute(0, 3, 1, 2).cpu()
+    assert rel_l2(got, ref) < 1e-3
+    assert rel_l2(g3.cpu(), g2.cpu()) < 1e-3
