@@ -637,7 +637,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
             if (sk_finish) {
                 // stream-K finisher: block seq0+1 wrote its partial of this tile as the first thing it did
                 if (tid == 0) {
-                    const unsigned* fl = sk.flags + seq0 + 1;
+                    unsigned* fl = sk.flags + seq0 + 1;
                     int spins = 0;
                     while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
                         __builtin_amdgcn_s_sleep(8);
@@ -646,6 +646,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                             break;
                         }
                     }
+                    // consumed: clear the flag, so that a replay of this launch with the SAME epoch (a captured hipGraph) waits for
+                    // the partial of the replay and not for the stale flag of the previous run
+                    __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 EW3_FENCE();
                 __builtin_amdgcn_s_barrier();

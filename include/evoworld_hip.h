@@ -102,7 +102,8 @@ const char* ew_gemm_last_kernel(void);
 void ew_set_gemm_debug(int flags);   /* measurement-only switches (bit0: skip stores, bit1: skip epilogue, bit2: no stream-K tail); 0 = normal */
 /* Generation 3 splits the last round of output tiles along K over its 256 persistent workgroups when whole-tile rounds would
  * leave > 4 % of the chip idle (stream-K tail: fp32 partial accumulators handed over through a library-owned uncached
- * workspace, one per (device, stream), allocated on first use: 84 MB).  Deterministic: the split depends on the shape only.
+ * workspace, one per (device, stream), allocated on first use: 84 MB + 67 MB for the 256-wide instance).  Deterministic: the
+ * split depends on the shape only.  A consumed hand-over flag is cleared by its consumer, so a captured launch can be replayed.
  * ew_gemm_streamk_status() synchronises and returns 0 when every hand-over completed, 1 if a finisher ever timed out
  * (results of that launch are invalid), -1 on a HIP error.  EW_G3_SK=0 in the environment switches the split off. */
 int ew_gemm_streamk_status(void);
