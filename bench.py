@@ -68,8 +68,12 @@ def cpu_baseline(max_threads=32, frames=4):
         m = UNetSpatioTemporalConditionModelRef()
     m = m.to_empty(device="cpu").eval()
     with torch.no_grad():
-        for p in m.parameters():
-            p.fill_(0.01)                      # timing only: values do not matter, denormals/NaNs must be avoided
+        gw = torch.Generator().manual_seed(1)
+        for n, p in m.named_parameters():      # timing only, but real-looking values: random matrices, unit norm scales, zero biases
+            if p.ndim > 1:
+                p.uniform_(-0.02, 0.02, generator=gw)
+            else:
+                p.fill_(1.0 if n.endswith("weight") else 0.0)
     g = torch.Generator().manual_seed(0)
     full = frames >= 50
     B, TS = (2, 25) if full else (1, frames)
