@@ -39,15 +39,20 @@ def main():
             torch.cuda.synchronize(); marks[name] = marks.get(name, 0.0) + time.perf_counter() - t0
             return r
         return w
-    loop = UnifiedLoopConsistencyPipeline(pipe, timed("depth_standin", st.depth_model), timed("vae_decode", st.frames_from_latents),
+    # the pipeline owns VAE + CLIP (reference flow: aug-noise draw, then latents, from one generator per window)
+    pipe.set_components(vae=st.vae, image_encoder=st.image_encoder)
+    loop = UnifiedLoopConsistencyPipeline(pipe, timed("depth_standin", st.depth_model),
                                           height=a.height, width=a.width, num_frames=25, num_segments=a.num_segments,
                                           num_inference_steps=a.steps)
     pipe.denoise = timed("denoise", pipe.denoise)
+    pipe.decode_latents = timed("vae_decode", pipe.decode_latents)
+    st.vae.encode = timed("vae_encode", st.vae.encode)
+    pipe._encode_image = timed("clip", pipe._encode_image)
     g = torch.Generator().manual_seed(0)
     start = (torch.rand(3, a.height, a.width, generator=g) * 2 - 1).to(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    frames = loop.process_episode(start, cam, timed("vae_encode+clip", st.image_latents_fn))
+    frames = loop.process_episode(start, cam)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     other = dt - sum(marks.values())

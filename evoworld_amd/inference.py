@@ -148,7 +148,7 @@ class UnifiedLoopConsistencyPipeline:
     `frames_from_latents(latents[1,T,4,h,w]) -> float [T,3,H,W] in [-1,1]` stands for the VAE decode (row N1);
     `depth_model(persp_u8 [F,384,512,3]) -> dict(depth, depth_conf, images, extrinsic, intrinsic)` stands for VGGT (row N4)."""
 
-    def __init__(self, pipeline, depth_model, frames_from_latents, height=576, width=1024, num_frames=25, num_segments=3,
+    def __init__(self, pipeline, depth_model, frames_from_latents=None, height=576, width=1024, num_frames=25, num_segments=3,
                  num_inference_steps=25, pano_size=(1000, 2000), face_res=512):
         self.nav = Navigator(pipeline, height, width, num_frames)
         self.depth_model, self.frames_from_latents = depth_model, frames_from_latents
@@ -164,14 +164,25 @@ class UnifiedLoopConsistencyPipeline:
         pers = self.equi2pers.batch(frames_u8, [{"pitch": 0, "roll": 0, "yaw": float(y)} for y in yaws])
         return pers, yaws / np.pi * 180.0
 
-    def process_episode(self, start_image, camera_params, image_latents_fn, save_dir=None, pos_scale=0.1, **pipe_kw):
+    def process_episode(self, start_image, camera_params, image_latents_fn=None, save_dir=None, pos_scale=0.1,
+                        save_segment_frames=False, **pipe_kw):
         """start_image float [3,H,W] in [-1,1]; camera_params [P,6] numpy: the UNSCALED RDF poses of camera_poses.txt
         (unified_loop_consistency.py:370-395), used as they are for the target yaws and the reprojection alignment; the
         Navigator / Plücker path gets the copy with xyz * pos_scale that the dataset hands out as batch['cam_traj']
-        (dataset/CameraTrajDataset.py:223,348).  `image_latents_fn(first_frame, memory [T,3,H,W]) ->
-        dict(image_latents=[1,1+T,4,h,w], image_embeddings=[1,1,X])` stands for VAE-encode + CLIP.
+        (dataset/CameraTrajDataset.py:223,348).
+
+        Default (image_latents_fn=None, the reference's flow): the PIPELINE owns `vae` and `image_encoder` and every window
+        is one `pipe(image, generator=torch.manual_seed(-1), memorized_pixel_values=...)` call, so the generator's first draw
+        is the [1+T,3,H,W] augmentation noise and its second the latents (pipeline_evoworld.py:596-600, then :663-673 ->
+        :401-435; navigator_evoworld.py:198) -- same seed, same noise as the reference.  Frames are decoded by the
+        pipeline's `decode_latents` (chunks of 8).
+        With `image_latents_fn(first_frame, memory [T,3,H,W]) -> dict(image_latents=[1,1+T,4,h,w], image_embeddings=[1,1,X])`
+        (stand-ins for VAE-encode + CLIP; decode through `frames_from_latents`) the conditioning is injected; the pipeline
+        still consumes draw #1 from the generator so that the latents stay the generator's second draw.
         Every generated frame is carried as the 8-bit image the reference's PIL frames hold (:418-419, navigator :214-226).
-        Returns all generated frames float [N,3,H,W] in [-1,1] (25 -> 49 -> 73 ...), values on the 8-bit grid."""
+        With save_dir and save_segment_frames, the per-segment dumps of :432-453 are written: predictions_{seg}/NNN.png
+        (the segment's new frames, NNN continuing at seg*(T-1)+1) and perspective_look_at_center_{seg}/NNN.png (the
+        pano->pers views fed to the depth network).  Returns all generated frames float [N,3,H,W] in [-1,1] (25 -> 49 -> 73 ...) on the 8-bit grid."""
         from . import ops
         dev = start_image.device
         camera_params = np.asarray(camera_params, dtype=np.float64)
@@ -182,16 +193,25 @@ class UnifiedLoopConsistencyPipeline:
         for seg in range(self.num_segments):
             start_idx, end_idx, _ = RP.calculate_segment_indices(seg)
             first = start_image if seg == 0 else ops.u8_hwc_to_f32_chw(all_u8[-1:])[0]    # pil_to_tensor(tensor_to_pil(.)) (:418-419)
-            cond = image_latents_fn(first, memory)
+            cond = image_latents_fn(first, memory) if image_latents_fn is not None else {}
             gens = self.nav.navigate_curve_path(cam_t, first, num_inference_steps=self.steps, memorized_images=memory[None],
                                                 infer_segment=True, segment_id=seg, output_type="latent", **cond, **pipe_kw)
             latents, _n = gens[-1]
-            frames_u8 = ops.f32_chw_to_u8_hwc(self.frames_from_latents(latents).float().contiguous())
+            if image_latents_fn is None and self.frames_from_latents is None:
+                pipe = self.nav.pipe
+                dec = pipe.decode_latents(latents, self.num_frames, 8)[0].permute(1, 0, 2, 3)      # [T,3,H,W] in [-1,1]
+            else:
+                dec = self.frames_from_latents(latents)
+            frames_u8 = ops.f32_chw_to_u8_hwc(dec.float().contiguous())
             if all_u8 is not None:
                 frames_u8 = frames_u8[1:]                                               # drop the duplicated first frame (:427-429)
+            if save_dir and save_segment_frames:                                        # :432-435, file index continues across segments
+                _save_u8_frames(frames_u8, os.path.join(save_dir, f"predictions_{seg}"), seg * (self.num_frames - 1))
             all_u8 = frames_u8 if all_u8 is None else torch.cat([all_u8, frames_u8], dim=0)
             if seg < self.num_segments - 1:
                 pers, target_yaws = self.convert_pano_to_pers(all_u8, camera_params, seg)
+                if save_dir and save_segment_frames:
+                    _save_u8_frames(pers, os.path.join(save_dir, f"perspective_look_at_center_{seg}"))   # :449-453
                 temp_cam = camera_params.copy()
                 s = max(0, end_idx - len(target_yaws))
                 temp_cam[s:end_idx, 4] = target_yaws[: end_idx - s]                        # :456-459
@@ -205,6 +225,14 @@ class UnifiedLoopConsistencyPipeline:
                 memory = torch.cat([start_image[None], mem24], dim=0)                      # [episode frame 1] + 24 reprojected (:277-279)
         self.last_frames_u8 = all_u8
         return ops.u8_hwc_to_f32_chw(all_u8)
+
+
+def _save_u8_frames(u8_hwc, d, start=0):
+    """NNN.png (1-based, offset by `start`) dumps of uint8 [F,H,W,3] frames (unified_loop_consistency.py:104-108,432-453)"""
+    from PIL import Image
+    os.makedirs(d, exist_ok=True)
+    for i, f in enumerate(u8_hwc.cpu().numpy()):
+        Image.fromarray(f).save(os.path.join(d, f"{i + start + 1:03}.png"))
 
 
 class _Sized:

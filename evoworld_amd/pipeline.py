@@ -46,6 +46,19 @@ class StableVideoDiffusionPipeline:
         self._device = unet.device or torch.device("cuda")
         self._progress = {}
 
+    def set_components(self, vae=None, image_encoder=None, feature_extractor=None):
+        """Plug in (or replace) the conditioning / decoding networks after construction: a stage provider of
+        `evoworld_amd.stages` hands its `vae` / `image_encoder` to the pipeline so that the pipeline itself runs the
+        reference's conditioning assembly (pipeline_evoworld.py:570-623), RNG draws included."""
+        if vae is not None:
+            self.vae = vae
+            self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1)
+        if image_encoder is not None:
+            self.image_encoder = image_encoder
+        if feature_extractor is not None:
+            self.feature_extractor = feature_extractor
+        return self
+
     @classmethod
     def from_pretrained(cls, path=None, unet=None, **kw):
         """The reference builds the pipeline from a diffusers folder and injects its own unet
@@ -106,10 +119,31 @@ class StableVideoDiffusionPipeline:
         return self._num_timesteps
 
     def check_inputs(self, image, height, width):
-        if not isinstance(image, torch.Tensor):
-            raise ValueError(f"`image` has to be a torch.Tensor on this path but is {type(image)}")
+        import PIL.Image
+        if not isinstance(image, (torch.Tensor, PIL.Image.Image, list)):                     # :387-396
+            raise ValueError("`image` has to be of type `torch.Tensor` or `PIL.Image.Image` or `List[PIL.Image.Image]` but is"
+                             f" {type(image)}")
         if height % 8 != 0 or width % 8 != 0:
             raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+
+    def _image_to_tensor(self, image, height, width):
+        """PIL image / list of PIL images -> float [B,3,H,W] in [-1,1] (what the reference callers pass as a tensor: ToTensor +
+        rescale, navigator_evoworld.py:436-437); resized to (height, width) with PIL's bilinear filter when the size differs
+        (VideoProcessor.preprocess semantics).  Tensors pass through."""
+        if isinstance(image, torch.Tensor):
+            return image
+        import numpy as np
+        import PIL.Image
+        imgs = image if isinstance(image, list) else [image]
+        out = []
+        for im in imgs:
+            if not isinstance(im, PIL.Image.Image):
+                raise ValueError(f"`image` list entries have to be PIL images but found {type(im)}")
+            im = im.convert("RGB")
+            if im.size != (width, height):
+                im = im.resize((width, height), PIL.Image.BILINEAR)
+            out.append(torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1).float() / 255.0 * 2 - 1)
+        return torch.stack(out).to(self._device)
 
     def _get_add_time_ids(self, fps, motion_bucket_id, noise_aug_strength, dtype, batch_size, num_videos_per_prompt, cfg):
         add_time_ids = [fps, motion_bucket_id, noise_aug_strength]
@@ -174,11 +208,11 @@ class StableVideoDiffusionPipeline:
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         num_frames = num_frames if num_frames is not None else self.unet.config.num_frames
         decode_chunk_size = decode_chunk_size if decode_chunk_size is not None else num_frames
-        if sigmas is not None:
-            raise NotImplementedError("custom sigmas are not supported (the reference never passes them)")
         if num_videos_per_prompt != 1:
-            raise NotImplementedError("num_videos_per_prompt != 1 is not used by the reference callers")
+            raise NotImplementedError("num_videos_per_prompt != 1: one video per call (the conditioning tensors of the reference "
+                                      "path -- plucker_embedding, memorized_pixel_values -- are not repeated there either)")
         self.check_inputs(image, height, width)
+        image = self._image_to_tensor(image, height, width)
         if plucker_embedding is None:
             raise ValueError("plucker_embedding [1,T,6,h,w] is required (evoworld conditioning)")
         batch_size = image.shape[0]
@@ -201,6 +235,11 @@ class StableVideoDiffusionPipeline:
                 dtype=flat.dtype)
             flat = flat + noise_aug_strength * noise.to(dev)                                 # :599-600
             image_latents = self.vae.encode(flat).latent_dist.mode().reshape(1, -1, 4, height // 8, width // 8)
+        elif image_noise is None and isinstance(generator, torch.Generator) and memorized_pixel_values is not None:
+            # injected conditioning: keep the reference's RNG order anyway -- the [1+T,3,H,W] augmentation-noise draw comes
+            # first (:596-600), so the latents below are the generator's SECOND draw, as in the reference
+            torch.randn((1 + memorized_pixel_values.shape[1],) + tuple(image.shape[1:]), generator=generator,
+                        device=generator.device, dtype=torch.float32)
         image_latents = image_latents.to(device=dev, dtype=torch.float32).clone()
         image_embeddings = image_embeddings.to(device=dev, dtype=torch.float32)
         if image_latents.shape[1] != num_frames + 1:
@@ -220,7 +259,11 @@ class StableVideoDiffusionPipeline:
 
         # --- 5-8. ids, timesteps, latents, guidance  (:646-682)
         added_time_ids = self._get_add_time_ids(fps - 1, motion_bucket_id, noise_aug_strength, torch.float32, 1, 1, True)
-        self.scheduler.set_timesteps(num_inference_steps, device="cpu")
+        if sigmas is not None:                                                               # retrieve_timesteps (:138-194)
+            self.scheduler.set_timesteps(sigmas=sigmas, device="cpu")
+            num_inference_steps = self.scheduler.num_inference_steps
+        else:
+            self.scheduler.set_timesteps(num_inference_steps, device="cpu")
         latents = self.prepare_latents(1, num_frames, self.unet.config.in_channels, height, width, torch.float32, dev,
                                        generator, latents)
         if cfg:

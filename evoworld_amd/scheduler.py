@@ -31,12 +31,23 @@ class EulerDiscreteScheduler:
     def from_pretrained(cls, *_a, **_k):
         return cls()
 
-    def set_timesteps(self, num_inference_steps, device=None, **_k):
+    def set_timesteps(self, num_inference_steps=None, device=None, timesteps=None, sigmas=None, **_k):
+        """num_inference_steps -> Karras schedule + final 0; or `sigmas` = a custom list INCLUDING its final value (the
+        diffusers 0.31 custom-sigma branch that `retrieve_timesteps` reaches, pipeline_evoworld.py:180-190): used as given,
+        timesteps = 0.25 * ln(sigma) over sigmas[:-1] (continuous timesteps + v-prediction)."""
         c = self.config
-        ramp = np.linspace(0, 1, num_inference_steps)
-        min_inv, max_inv = c.sigma_min ** (1 / c.rho), c.sigma_max ** (1 / c.rho)
-        sig = (max_inv + ramp * (min_inv - max_inv)) ** c.rho                     # Karras et al. (2022) eq. 5
-        sig = np.concatenate([sig, [0.0]]).astype(np.float32)
+        if timesteps is not None:
+            raise ValueError("custom `timesteps` are not supported by the continuous-timestep SVD configuration; pass `sigmas`")
+        if sigmas is not None:
+            sig = np.asarray(sigmas, dtype=np.float32)
+            if sig.ndim != 1 or sig.size < 2 or not (sig[:-1] > 0).all():
+                raise ValueError("`sigmas` must be a 1-D list of positive values followed by the final sigma")
+            num_inference_steps = int(sig.size - 1)
+        else:
+            ramp = np.linspace(0, 1, num_inference_steps)
+            min_inv, max_inv = c.sigma_min ** (1 / c.rho), c.sigma_max ** (1 / c.rho)
+            sig = (max_inv + ramp * (min_inv - max_inv)) ** c.rho                     # Karras et al. (2022) eq. 5
+            sig = np.concatenate([sig, [0.0]]).astype(np.float32)
         self.sigmas = torch.from_numpy(sig)                                       # kept on host: step scalars
         self.timesteps = torch.tensor([0.25 * float(np.log(s)) for s in sig[:-1]], dtype=torch.float32)
         if device is not None:

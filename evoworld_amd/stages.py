@@ -7,11 +7,29 @@ object with the same three methods as `SyntheticStages`.
 the entry points (`unified_loop_consistency.py`, `run_single_segment.sh`, `run_unified_pipeline.sh`) run end to end on a box
 that has no checkpoints (there is no network in the build environment).  All of it runs on the device.
 """
+from types import SimpleNamespace
+
 import numpy as np
 import torch
 import torch.nn.functional as F
 
 from .geometry import xyz_euler_to_four_by_four_matrix_batch
+
+
+class _SyntheticVae:
+    """Duck type of the two VAE calls the pipeline makes (pipeline_evoworld.py:307-328 `vae.encode(x).latent_dist.mode()`,
+    :358-385 `vae.decode(z, num_frames=k).sample`) over the weight-free colour mixes of `SyntheticStages`."""
+
+    def __init__(self, stages):
+        self._s = stages
+        self.config = SimpleNamespace(scaling_factor=1.0, block_out_channels=(1, 1, 1, 1))
+
+    def encode(self, x):
+        lat = torch.einsum("oc,nchw->nohw", self._s.enc.to(x), F.avg_pool2d(x, 8))
+        return SimpleNamespace(latent_dist=SimpleNamespace(mode=lambda: lat))
+
+    def decode(self, z, num_frames=1):
+        return SimpleNamespace(sample=self._s.frames_from_latents(z[None]))
 
 
 class SyntheticStages:
@@ -20,6 +38,18 @@ class SyntheticStages:
         # fixed 3->4 / 4->3 colour mixes standing for the VAE's channel change
         self.enc = torch.tensor([[0.6, 0.3, 0.1], [-0.2, 0.7, -0.5], [0.5, -0.5, 0.0], [0.3, 0.3, 0.3]])
         self.dec = torch.linalg.pinv(self.enc)
+        # the pipeline's own components (`StableVideoDiffusionPipeline(unet, vae=stages.vae, image_encoder=stages.image_encoder)`):
+        # with them the pipeline performs the reference's conditioning assembly itself, RNG draws included
+        self.vae = _SyntheticVae(self)
+        self.image_encoder = self._embed
+        self.feature_extractor = None
+
+    def _embed(self, pixel_values):
+        """CLIP stand-in on the pipeline's 224x224 normalised input -> .image_embeds [N, xdim]"""
+        emb = F.adaptive_avg_pool2d(pixel_values.float(), (16, self.xdim // 16 // 3 + 1)).flatten(1)[:, : self.xdim]
+        if emb.shape[1] < self.xdim:
+            emb = F.pad(emb, (0, self.xdim - emb.shape[1]))
+        return SimpleNamespace(image_embeds=emb)
 
     # VAE encode of [first frame + 25 memory frames] and CLIP embedding of the first frame
     # (pipeline_evoworld.py:214-263 `_encode_vae_image`, :186-212 `_encode_image`)
@@ -58,26 +88,32 @@ class HipStages(SyntheticStages):
     network (VGGT-1B, row N4) stays the synthetic stand-in.  Weights: `svd_path/vae`, `svd_path/image_encoder` when those
     diffusers folders exist, otherwise random-init of the full architectures (timing / plumbing runs)."""
 
-    def __init__(self, svd_path=None, device="cuda", seed=0, noise_aug_strength=0.02, **kw):
+    def __init__(self, svd_path=None, device="cuda", seed=0, noise_aug_strength=0.02, vae_config=None, clip_config=None, **kw):
         super().__init__(**kw)
         import os
         from .clip import CLIPVisionModelWithProjection
         from .vae import AutoencoderKLTemporalDecoder
         have = lambda sub: bool(svd_path) and os.path.isdir(os.path.join(svd_path, sub))
+        # vae_config / clip_config: overrides of the random-init architectures (tests use reduced widths)
         self.vae = (AutoencoderKLTemporalDecoder.from_pretrained(svd_path, subfolder="vae", device=device) if have("vae")
-                    else AutoencoderKLTemporalDecoder.from_random(seed=seed, device=device))
+                    else AutoencoderKLTemporalDecoder.from_random(seed=seed, device=device, **(vae_config or {})))
         self.clip = (CLIPVisionModelWithProjection.from_pretrained(svd_path, subfolder="image_encoder", device=device)
-                     if have("image_encoder") else CLIPVisionModelWithProjection.from_random(seed=seed, device=device))
+                     if have("image_encoder") else CLIPVisionModelWithProjection.from_random(seed=seed, device=device, **(clip_config or {})))
+        self.image_encoder = self.clip
         self.noise_aug_strength = noise_aug_strength
         self.decode_chunk_size = 8
 
-    def image_latents_fn(self, first, memory):
-        """pipeline_evoworld.py:570-623: CLIP embedding of the first frame; VAE mode() of [first | memory] + 0.02 * noise"""
+    def image_latents_fn(self, first, memory, image_noise=None):
+        """pipeline_evoworld.py:570-623: CLIP embedding of the first frame; VAE mode() of [first | memory] + 0.02 * noise.
+        Stand-alone form for timing the stage; the episode / CLI paths hand `vae` and `image_encoder` to the pipeline instead,
+        which draws the augmentation noise from the window's generator BEFORE the latents, as the reference does
+        (pipeline_evoworld.py:596-600 then :663-673)."""
         from .clip import encode_image_preprocess
         x = torch.cat([first[None], memory], 0)                                         # [-1,1]
         emb = self.clip(encode_image_preprocess(x[:1] / 2 + 0.5)).image_embeds[:, None]
-        noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(-1 & 0x7fffffff)).to(x.device)
-        lat = self.vae.encode(x + self.noise_aug_strength * noise).latent_dist.mode()
+        if image_noise is None:
+            image_noise = torch.randn(x.shape, generator=torch.manual_seed(-1))
+        lat = self.vae.encode(x + self.noise_aug_strength * image_noise.to(x.device)).latent_dist.mode()
         return dict(image_latents=lat[None], image_embeddings=emb)
 
     def frames_from_latents(self, latents):

@@ -77,6 +77,31 @@ def test_scheduler_known_answers():
     assert torch.allclose(out.pred_original_sample, c_skip * x + c_out * v, rtol=1e-6, atol=1e-6)
 
 
+def test_scheduler_custom_sigmas_and_stage_duck_types():
+    """`sigmas=` through retrieve_timesteps (pipeline_evoworld.py:180-190): used as given, timesteps = 0.25 ln sigma; the
+    synthetic stage provider exposes the pipeline's vae / image_encoder duck types (host tensors: no kernel involved)."""
+    from evoworld_amd.scheduler import EulerDiscreteScheduler
+    from evoworld_amd.stages import SyntheticStages
+    s = EulerDiscreteScheduler()
+    s.set_timesteps(sigmas=[700.0, 20.0, 1.0, 0.0])
+    assert s.num_inference_steps == 3 and s.sigmas.tolist() == [700.0, 20.0, 1.0, 0.0]
+    np.testing.assert_allclose(s.timesteps.numpy(), 0.25 * np.log([700.0, 20.0, 1.0]), rtol=1e-6, atol=1e-7)
+    s2 = EulerDiscreteScheduler()
+    s2.set_timesteps(5)
+    s.set_timesteps(sigmas=s2.sigmas.tolist())
+    assert torch.equal(s.sigmas, s2.sigmas) and torch.equal(s.timesteps, s2.timesteps)
+    with pytest.raises(ValueError):
+        s.set_timesteps(sigmas=[1.0])
+    with pytest.raises(ValueError):
+        s.set_timesteps(timesteps=[1, 2])
+    st = SyntheticStages(cross_attention_dim=64)
+    x = torch.rand(3, 3, 32, 64) * 2 - 1
+    z = st.vae.encode(x).latent_dist.mode()
+    assert z.shape == (3, 4, 4, 8) and len(st.vae.config.block_out_channels) == 4
+    assert st.vae.decode(z, num_frames=3).sample.shape == (3, 3, 32, 64)
+    assert st.image_encoder(torch.rand(1, 3, 224, 224)).image_embeds.shape == (1, 64)
+
+
 def test_geometry_and_rays_golden(golden_dir):
     from evoworld_amd.geometry import xyz_euler_to_four_by_four_matrix_batch, xyz_euler_to_three_by_four_matrix_batch
     from evoworld_amd.plucker import equirectangular_to_ray

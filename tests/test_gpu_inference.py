@@ -271,3 +271,120 @@ def test_cli_single_segment_is_the_reference_single_segment_path(tmp_path, golde
     assert torch.equal(seen["memory"][0, 0].cpu(), px(imgs[1])) and torch.equal(seen["memory"][0, 24].cpu(), px(renders[23]))
     assert len(os.listdir(tmp_path / "out" / "case_000" / "predictions")) == 25
     assert len(os.listdir(tmp_path / "out" / "case_000" / "predictions_gt")) == 25
+
+
+def test_episode_window_rng_order_matches_reference():
+    """C3 / VERDICT r2 #2: one window through Navigator.move_forward with the HIP VAE + CLIP owned by the PIPELINE.  The
+    reference draws from ONE generator re-seeded per window (navigator_evoworld.py:198): draw #1 the [1+T,3,H,W] augmentation
+    noise (pipeline_evoworld.py:596-600), draw #2 the latents (:663-673 -> :401-435).  Asserts the tensors the pipeline
+    actually consumed are exactly those two draws."""
+    from evoworld_amd.clip import DEFAULT_CLIP_CONFIG
+    from evoworld_amd.inference import Navigator
+    from evoworld_amd.pipeline import StableVideoDiffusionPipeline
+    from evoworld_amd.stages import HipStages
+    from evoworld_amd.unet import DEFAULT_CONFIG, UNetSpatioTemporalConditionModel, random_state_dict
+    from oracle.unet_ref import tiny_config
+    from oracle.vae_ref import tiny_vae_config
+    cfg = tiny_config()
+    cfg["num_frames"] = 25
+    H, W, T = 128, 256, 25
+    unet = UNetSpatioTemporalConditionModel(**cfg).load_state_dict(random_state_dict({**DEFAULT_CONFIG, **cfg}, 0), device=DEV)
+    st = HipStages(device=DEV, vae_config=tiny_vae_config(),
+                   clip_config=dict(DEFAULT_CLIP_CONFIG, num_hidden_layers=1, projection_dim=cfg["cross_attention_dim"]),
+                   cross_attention_dim=cfg["cross_attention_dim"])
+    pipe = StableVideoDiffusionPipeline(unet=unet).set_components(vae=st.vae, image_encoder=st.image_encoder)
+    nav = Navigator(pipe, height=H, width=W, num_frames=T)
+    g = torch.Generator().manual_seed(11)
+    image = (torch.rand(3, H, W, generator=g) * 2 - 1).to(DEV)
+    memory = (torch.rand(1, T, 3, H, W, generator=g) * 2 - 1).to(DEV)
+    nav.memorized_images = memory
+    path = torch.cat([torch.randn(25, 3, generator=g) * 0.1, torch.zeros(25, 1), torch.linspace(90, 120, 25)[:, None], torch.zeros(25, 1)], 1)
+    seen = {}
+    enc0, den0 = st.vae.encode, pipe.denoise
+
+    def enc_spy(x):
+        seen["vae_in"] = x.clone()
+        return enc0(x)
+
+    def den_spy(latents, *a, **k):
+        seen["latents"] = latents.clone()
+        return den0(latents, *a, **k)
+    st.vae.encode, pipe.denoise = enc_spy, den_spy
+    try:
+        frames, n = nav.move_forward(image, path, num_inference_steps=1, use_memory=True, output_type="latent")
+    finally:
+        st.vae.encode, pipe.denoise = enc0, den0
+    gen = torch.manual_seed(-1)                                                    # the reference's per-window generator
+    noise = torch.randn([1 + T, 3, H, W], generator=gen)                           # draw #1
+    lat = torch.randn([1, T, 4, H // 8, W // 8], generator=gen)                    # draw #2
+    flat = torch.cat([image[None], memory[0]], 0)                                  # (x/2+0.5)*2-1 == x up to one rounding
+    want_in = (flat / 2.0 + 0.5) * 2.0 - 1.0 + 0.02 * noise.to(DEV)
+    assert torch.equal(seen["vae_in"], want_in)
+    assert torch.equal(seen["latents"].cpu(), lat * pipe.scheduler.init_noise_sigma)
+    assert n == 25 and frames.shape == (1, T, 4, H // 8, W // 8) and torch.isfinite(frames).all()
+    # injected conditioning (stand-in stages) must leave the latents on the generator's SECOND draw too
+    seen.clear()
+    pipe.denoise = den_spy
+    try:
+        il = st.vae.encode(want_in).latent_dist.mode()[None]
+        nav.move_forward(image, path, num_inference_steps=1, use_memory=True, output_type="latent", image_latents=il,
+                         image_embeddings=torch.zeros(1, 1, cfg["cross_attention_dim"]))
+    finally:
+        pipe.denoise = den0
+    assert torch.equal(seen["latents"].cpu(), lat * pipe.scheduler.init_noise_sigma)
+
+
+def test_process_episode_component_mode_and_segment_dumps(tiny, tmp_path):
+    """C3 in the reference's flow: the pipeline owns vae / image_encoder (stage stand-ins here), two segments, and the
+    per-segment dump directories of unified_loop_consistency.py:432-453."""
+    import os
+    from evoworld_amd.inference import UnifiedLoopConsistencyPipeline
+    from evoworld_amd.stages import SyntheticStages
+    cfg, pipe = tiny
+    H, W, T = 128, 256, 25
+    i = np.arange(60, dtype=np.float64)
+    cam = np.stack([0.04 * i * np.sin(i / 9), 0 * i, 0.04 * i * np.cos(i / 9), 0 * i, 95 + 3.6 * i, 0 * i], 1)
+    st = SyntheticStages(cross_attention_dim=cfg["cross_attention_dim"], camera_params=cam, depth_hw=(48, 64))
+    saved = (pipe.vae, pipe.image_encoder, pipe.vae_scale_factor)
+    pipe.set_components(vae=st.vae, image_encoder=st.image_encoder)
+    try:
+        loop = UnifiedLoopConsistencyPipeline(pipe, st.depth_model, height=H, width=W, num_frames=T, num_segments=2,
+                                              num_inference_steps=1, pano_size=(64, 128), face_res=32)
+        start = (torch.rand(3, H, W, generator=torch.Generator().manual_seed(3)) * 2 - 1).to(DEV)
+        frames = loop.process_episode(start, cam, save_dir=str(tmp_path), save_segment_frames=True)
+        again = loop.process_episode(start, cam)
+    finally:
+        pipe.vae, pipe.image_encoder, pipe.vae_scale_factor = saved
+    assert frames.shape == (49, 3, H, W) and torch.isfinite(frames).all() and torch.equal(frames, again)
+    assert sorted(os.listdir(tmp_path / "predictions_0")) == [f"{k:03}.png" for k in range(1, 26)]
+    assert sorted(os.listdir(tmp_path / "predictions_1")) == [f"{k:03}.png" for k in range(25, 49)]      # continues at seg*(T-1)+1
+    assert sorted(os.listdir(tmp_path / "perspective_look_at_center_0")) == [f"{k:03}.png" for k in range(1, 26)]
+    got = np.asarray(Image.open(tmp_path / "predictions_1" / "025.png"))
+    assert np.array_equal(got, loop.last_frames_u8[25].cpu().numpy())
+
+
+def test_pipeline_accepts_pil_images_and_custom_sigmas(tiny):
+    """pipeline_evoworld.py:387-399 (PIL / list-of-PIL `image`) and :138-194 (`sigmas` through retrieve_timesteps)."""
+    cfg, pipe = tiny
+    H, W, T = 128, 256, 25
+    g = torch.Generator().manual_seed(5)
+    arr = (torch.rand(H, W, 3, generator=g) * 255).to(torch.uint8).numpy()
+    pil = Image.fromarray(arr)
+    as_tensor = (torch.from_numpy(arr).permute(2, 0, 1).float() / 255 * 2 - 1)[None].to(DEV)
+    kw = dict(height=H, width=W, num_frames=T, output_type="latent", plucker_embedding=torch.randn(1, T, 6, H // 8, W // 8, generator=g),
+              image_latents=torch.randn(1, T + 1, 4, H // 8, W // 8, generator=g),
+              image_embeddings=torch.randn(1, 1, cfg["cross_attention_dim"], generator=g),
+              latents=torch.randn(1, T, 4, H // 8, W // 8, generator=g))
+    a = pipe(as_tensor, num_inference_steps=2, **kw).frames
+    b = pipe(pil, num_inference_steps=2, **kw).frames
+    c = pipe([pil], num_inference_steps=2, **kw).frames
+    assert torch.equal(a, b) and torch.equal(a, c)
+    with pytest.raises(ValueError):
+        pipe(arr, num_inference_steps=2, **kw)
+    # custom sigmas == the scheduler's own Karras schedule -> identical result; a different schedule -> different, finite
+    pipe.scheduler.set_timesteps(2)
+    own = pipe.scheduler.sigmas.tolist()
+    d = pipe(as_tensor, sigmas=own, **kw).frames
+    assert torch.equal(a, d) and pipe.num_timesteps == 2
+    e = pipe(as_tensor, sigmas=[700.0, 20.0, 1.0, 0.0], **kw).frames
+    assert pipe.num_timesteps == 3 and torch.isfinite(e).all() and not torch.equal(a, e)

@@ -96,12 +96,14 @@ def run_single_segment(args, ep, pipe, unet, dev, out_dir, synthetic):
     stages = load_stages(args.stages, args, cross_attention_dim=unet._cfg["cross_attention_dim"], camera_params=cam)
     rays = torch.tensor(equirectangular_to_ray(args.height // 8, args.width // 8)).float().to(dev)
     args.mask_mem = False                                                                   # :532
-    cond = stages.image_latents_fn(batch["pixel_values"][0, 0], batch["memorized_pixel_values"][0])
+    pipe.set_components(vae=stages.vae, image_encoder=stages.image_encoder, feature_extractor=stages.feature_extractor)
     torch.cuda.synchronize()
     t0 = time.time()
+    # the pipeline encodes [first frame | memory] itself (aug-noise draw, VAE mode, CLIP) as the reference's does
     latents = process_batch(batch, args, pipe, rays, torch.float32, None, os.path.basename(ep), output_type="latent",
-                            num_inference_steps=args.num_inference_steps, **cond)
-    frames_u8 = ops.f32_chw_to_u8_hwc(stages.frames_from_latents(latents).float().contiguous())
+                            num_inference_steps=args.num_inference_steps)
+    dec = pipe.decode_latents(latents, args.num_frames, 8)[0].permute(1, 0, 2, 3)                  # [T,3,H,W] in [-1,1]
+    frames_u8 = ops.f32_chw_to_u8_hwc(dec.float().contiguous())
     torch.cuda.synchronize()
     dt = time.time() - t0
     if args.save_frames:
@@ -121,13 +123,16 @@ def run_episode(args, ep, pipe, unet, dev, out_dir, synthetic):
     if start is None:
         g = torch.Generator().manual_seed(0)
         start = (torch.rand(3, args.height, args.width, generator=g) * 2 - 1).to(dev)
-    loop = UnifiedLoopConsistencyPipeline(pipe, stages.depth_model, stages.frames_from_latents, height=args.height,
+    pipe.set_components(vae=stages.vae, image_encoder=stages.image_encoder, feature_extractor=stages.feature_extractor)
+    loop = UnifiedLoopConsistencyPipeline(pipe, stages.depth_model, height=args.height,
                                           width=args.width, num_frames=args.num_frames, num_segments=args.num_segments,
                                           num_inference_steps=args.num_inference_steps)
     torch.cuda.synchronize()
     t0 = time.time()
-    # the unscaled poses go in; process_episode derives the pos-scaled Navigator / Plücker path itself (pos_scale = 0.1)
-    frames = loop.process_episode(start, cam, stages.image_latents_fn, save_dir=out_dir if args.save_frames else None)
+    # the unscaled poses go in; process_episode derives the pos-scaled Navigator / Plücker path itself (pos_scale = 0.1);
+    # --save_frames also writes the reference's per-segment dumps predictions_{seg}/ and perspective_look_at_center_{seg}/
+    frames = loop.process_episode(start, cam, save_dir=out_dir if args.save_frames else None,
+                                  save_segment_frames=args.save_frames)
     torch.cuda.synchronize()
     dt = time.time() - t0
     if args.save_frames:
