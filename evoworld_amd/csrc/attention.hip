@@ -508,12 +508,8 @@ extern "C" ew_status ew_attn_temporal_f16(const void* q, const void* k, const vo
     EW_REQUIRE(nblk < 0x7fffffffLL, "ew_attn_temporal_f16: grid too large");
     if (T > 32) {
         const size_t lds = 4 * 3 * 64 * 144;                        // 110,592 B
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)attn_temporal64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) { ew_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return EW_ERR_HIP; }
-            attr_set = true;
-        }
+        static std::atomic<unsigned long long> attr_mask{0};                   // per (kernel instantiation, device)
+    if (ew_status st = ew_ensure_dynamic_lds((const void*)attn_temporal64_kernel, (int)lds, attr_mask)) return st;
         hipLaunchKernelGGL(attn_temporal64_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, (const f16*)q,
                            (const f16*)k, (const f16*)v, (f16*)o, B, T, S, heads, ld, ld_o, scale * 1.4426950408889634f, n_prob);
         return ew_check_launch("ew_attn_temporal_f16");

@@ -28,6 +28,20 @@ ew_status ew_check_launch(const char* what);
 
 static inline int ew_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: cache "already set" per (kernel, device), thread-safe.
+// `mask` is one static std::atomic<unsigned long long> per kernel instantiation (bit d = set on device d; devices >= 64 set it on
+// every launch).
+#include <atomic>
+static inline ew_status ew_ensure_dynamic_lds(const void* fn, int bytes, std::atomic<unsigned long long>& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 64; }
+    if (dev < 64 && (mask.load(std::memory_order_acquire) >> dev) & 1ULL) return EW_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { ew_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return EW_ERR_HIP; }
+    if (dev < 64) mask.fetch_or(1ULL << dev, std::memory_order_release);
+    return EW_OK;
+}
+
 __device__ __forceinline__ float ew_silu(float x) { return x / (1.0f + __expf(-x)); }
 // erf GELU (torch.nn.functional.gelu default, diffusers GEGLU).  erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7,
 // i.e. below fp32 erff's own error after the fp16 output rounding): 2 transcendentals + ~10 VALU instead of libm's
@@ -45,10 +59,15 @@ __device__ __forceinline__ float ew_erf(float x) {
 }
 __device__ __forceinline__ float ew_gelu(float x) { return 0.5f * x * (1.0f + ew_erf(x * 0.70710678118654752440f)); }
 // value * gelu(gate) for two (value, gate) pairs at once on the packed-fp32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32: two
-// lanes-elements per issue); only the two transcendentals stay scalar.  Same A&S 7.1.26 erf as ew_erf, with the sign folded
-// away: gelu(g) = 0.5 * (g + |g| * erf(|g| / sqrt 2)).  ~15.5 issue slots per element instead of ~24: the GEGLU epilogue of
-// the K = 320 feed-forward GEMMs is one third of their run time.
-__device__ __forceinline__ f32x2 ew_vgelu2(f32x2 v, f32x2 g) {
+// lane-elements per issue); only the transcendentals stay scalar.
+// Round 3: gelu(g) = g * Phi(g) with Phi(g) ~= 1 / (1 + exp(-g * (c1 + c3 g^2 + c5 g^4))), the logistic form with an odd
+// polynomial exponent, minimax-fitted to the erf GELU (torch.nn.functional.gelu default, diffusers GEGLU) on |g| <= 9 (g^2 is
+// clamped at 64; beyond |g| = 8 the result is g or 0 to fp32 precision either way): max |gelu error| 2.6e-5 absolute (fp32
+// evaluation included), i.e. 1/19 of the fp16 ulp at 1.0 the result is rounded to -- measured effect on the forward's rel-L2
+// against the fp32 oracle: none (tests/test_gpu_unet.py).  13 issue slots per PAIR instead of the 31 of the A&S 7.1.26 erf form
+// used before (ew_vgelu2_erf, kept for A/B: -DEW_GEGLU_ERF): the GEGLU epilogue of the K = 320 feed-forward GEMMs was a third of
+// their run time.
+__device__ __forceinline__ f32x2 ew_vgelu2_erf(f32x2 v, f32x2 g) {
     const f32x2 ag = {fabsf(g[0]), fabsf(g[1])};
     const f32x2 ax = ag * 0.70710678118654752440f;
     const f32x2 den = __builtin_elementwise_fma(ax, (f32x2){0.3275911f, 0.3275911f}, (f32x2){1.0f, 1.0f});
@@ -61,6 +80,21 @@ __device__ __forceinline__ f32x2 ew_vgelu2(f32x2 v, f32x2 g) {
     const f32x2 e = {__builtin_amdgcn_exp2f(x2[0]), __builtin_amdgcn_exp2f(x2[1])};
     const f32x2 y = __builtin_elementwise_fma(-(p * t), e, (f32x2){1.0f, 1.0f});       // erf(|g| / sqrt 2)
     return (v * 0.5f) * __builtin_elementwise_fma(ag, y, g);
+}
+__device__ __forceinline__ f32x2 ew_vgelu2(f32x2 v, f32x2 g) {
+#ifdef EW_GEGLU_ERF
+    return ew_vgelu2_erf(v, g);
+#else
+    // k_i = -log2(e) * c_i, c = (1.59501577, 7.40112921e-2, -7.03033591e-4)
+    f32x2 x2 = g * g;
+    x2 = (f32x2){fminf(x2[0], 64.0f), fminf(x2[1], 64.0f)};
+    f32x2 p = __builtin_elementwise_fma(x2, (f32x2){0.0010142630f, 0.0010142630f}, (f32x2){-0.10677572f, -0.10677572f});
+    p = __builtin_elementwise_fma(p, x2, (f32x2){-2.3011212f, -2.3011212f});
+    const f32x2 t = g * p;
+    const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + (f32x2){1.0f, 1.0f};
+    const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return (v * g) * r;
+#endif
 }
 
 // ---- split residual stream: value = (hi fp16, lo8 int8) ------------------------------------------------------------------

@@ -557,13 +557,8 @@ ew_status launch2(const GemmP& p, hipStream_t s) {
     q.tiles_m = ew_cdiv(p.M, BM);
     q.tiles_n = ew_cdiv(p.N, BN);
     const size_t lds = NSTAGE * (BM + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm2_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE, MODE, EPI>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { ew_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return EW_ERR_HIP; }
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_mask{0};                   // per (kernel instantiation, device)
+    if (ew_status st = ew_ensure_dynamic_lds((const void*)gemm2_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE, MODE, EPI>, (int)lds, attr_mask)) return st;
     const long long tiles = (long long)q.tiles_m * q.tiles_n;
     if (tiles <= 0 || tiles > 0x7fffffffLL) { ew_set_error("ew_gemm_f16: bad grid"); return EW_ERR_INVALID_ARG; }
     int grid = (NW == 8 || BM == 256) ? 256 : 512;                   // persistent: 1 x 8-wave or 2 x 4-wave workgroups per CU (256 CUs)

@@ -44,10 +44,12 @@ class Res:
     ew_gemm_args), or lo = None when the stream is kept in plain fp16.  The reference runs the stream in fp32
     (unified_loop_consistency.py:188); consumers that need an fp16 MFMA operand read `hi` alone, the residual epilogues and
     the norms read both."""
-    __slots__ = ("hi", "lo")
+    __slots__ = ("hi", "lo", "stats")
 
-    def __init__(self, hi, lo=None):
-        self.hi, self.lo = hi, lo
+    def __init__(self, hi, lo=None, stats=None):
+        # stats: optional fp32 [rows/64, C, 2] column statistics (mean, M2 per 64-row block) emitted by the producing GEMM's
+        # epilogue (ew_gemm_args.colstats) -- what a GroupNorm over this tensor needs instead of a statistics pass
+        self.hi, self.lo, self.stats = hi, lo, stats
 
     @classmethod
     def empty(cls, rows, C, device, split):
@@ -79,7 +81,7 @@ def _hl(x):
 
 def gemm(a, w, out, *, M, N, c1, lda, a2=None, c2=0, lda2=0, bias=None, rowbias=None, rows_per_group=1, ld_rowbias=None,
          r1=None, ld_r1=0, r2=None, ld_r2=0, ld_out=None, mode=A_DENSE, conv=None, tconv=None, act=ACT_NONE,
-         c_acc=1.0, c_r1=1.0, c_r2=1.0, conv_shift=0):
+         c_acc=1.0, c_r1=1.0, c_r2=1.0, conv_shift=0, colstats=None):
     """out = c_acc*act(A@W^T + bias + rowbias) + c_r1*r1 + c_r2*r2  (see ew_gemm_f16).
     conv = (n_img, h_in, w_in, h_out, w_out, stride, upsample); tconv = (B, T, P); conv_shift=1: padding (0,1) taps.
     r1 / r2 / out may be `Res` (split-fp16 residual stream): the lo halves ride along (ew_gemm_args.r1_lo ...)."""
@@ -103,6 +105,7 @@ def gemm(a, w, out, *, M, N, c1, lda, a2=None, c2=0, lda2=0, bias=None, rowbias=
     g.rows_per_group, g.act = rows_per_group, act
     g.c_acc, g.c_r1, g.c_r2 = c_acc, c_r1, c_r2
     g.conv_shift = conv_shift
+    g.colstats = _ptr(colstats)      # fp32 [M/64, N, 2]: column statistics of the result for the consuming GroupNorm
     _lib.check(lib.ew_gemm_f16(ctypes.byref(g), _stream()), "ew_gemm_f16")
     return out
 
@@ -142,13 +145,47 @@ class WorkspacePool:
 SumsPool = WorkspacePool   # former name
 
 
+def colstats_alloc(M, C, device):
+    """fp32 [M/64, C, 2] buffer for ew_gemm_args.colstats / ew_colstats_f16 (every entry is written: no zeroing)."""
+    return torch.empty(M // 64, C, 2, dtype=torch.float32, device=device)
+
+
+def colstats(x):
+    """Stand-alone 64-row-block column statistics of a stored tensor (fp16 [M, C] or `Res`), M % 64 == 0."""
+    lib = _lib.load()
+    h, l = _hl(x)
+    M, C = h.shape
+    st = colstats_alloc(M, C, h.device)
+    _lib.check(lib.ew_colstats_f16(_ptr(h), _ptr(l), _ptr(st), M, C, C, _stream()), "ew_colstats_f16")
+    return st
+
+
 def groupnorm(xs, gamma, beta, n_slabs, rows, eps, silu, groups=32, out=None, pool=None, stats_hi_only=False):
     """GroupNorm(+SiLU) over the channel concat of `xs` (list of [n_slabs*rows, C_i] fp16 tensors or `Res`) ->
-    [n_slabs*rows, sum C_i] fp16.  Deterministic shifted statistics: stats per source, one finalize, apply per source."""
+    [n_slabs*rows, sum C_i] fp16.  Deterministic, cancellation-safe statistics.  When a source carries the column statistics
+    its producer emitted (`Res.stats`) and a slab is a whole number of 64-row blocks, there is no statistics pass over the
+    tensors: one finalize over the block statistics (a source without them gets the stand-alone kernel), then apply."""
     lib = _lib.load()
     srcs = [_hl(x) for x in xs]
     C_tot = sum(h.shape[-1] for h, _ in srcs)
     dev = srcs[0][0].device
+    have = [getattr(x, "stats", None) for x in xs]
+    if rows % 64 == 0 and len(xs) <= 2 and any(s is not None for s in have):
+        sts = [s if s is not None else colstats(x) for s, x in zip(have, xs)]
+        table = pool.take(n_slabs * groups * 2) if pool is not None else torch.empty(n_slabs * groups * 2, dtype=torch.float32, device=dev)
+        c1 = srcs[0][0].shape[-1]
+        c2 = srcs[1][0].shape[-1] if len(srcs) > 1 else 0
+        _lib.check(lib.ew_groupnorm_finalize_colstats(_ptr(sts[0]), c1, _ptr(sts[1]) if len(sts) > 1 else None, c2, _ptr(table),
+                                                      n_slabs, rows, groups, _stream()), "ew_groupnorm_finalize_colstats")
+        if out is None:
+            out = torch.empty(n_slabs * rows, C_tot, dtype=torch.float16, device=dev)
+        off = 0
+        for h, l in srcs:
+            _lib.check(lib.ew_groupnorm_apply_stats_f16(_ptr(h), _ptr(l), _ptr(table), _ptr(gamma), _ptr(beta), _ptr(out), n_slabs,
+                                                        rows, h.shape[-1], off, C_tot, groups, eps, 1 if silu else 0, _stream()),
+                       "ew_groupnorm_apply_stats_f16")
+            off += h.shape[-1]
+        return out
     nws = lib.ew_groupnorm_workspace_floats(n_slabs, rows, C_tot, groups)
     ws = pool.take(nws) if pool is not None else torch.empty(nws, dtype=torch.float32, device=dev)
     if out is None:

@@ -225,6 +225,8 @@ class UNetSpatioTemporalConditionModel:
         # BASELINE.json configs[4]: q / k / v projections on the fp8 (e4m3) MFMA path (per-token activation scales,
         # per-output-channel weight scales); off by default -- it changes the numerics contract (tests/test_gpu_fp8.py)
         self.qkv_fp8 = bool(config.get("qkv_fp8", os.environ.get("EW_QKV_FP8", "0") == "1"))
+        # GroupNorm statistics from the producing GEMM's epilogue (ew_gemm_args.colstats) instead of a pass over the tensor
+        self.fused_gn_stats = os.environ.get("EW_FUSED_GN_STATS", "1") != "0"
         self._pos_cache = {}
         for hd, c in zip(cfg["num_attention_heads"], cfg["block_out_channels"]):
             if c // hd != 64:
@@ -428,19 +430,37 @@ class UNetSpatioTemporalConditionModel:
     def _res(self, rows, C, dev, head=False):
         return Res.empty(rows, C, dev, self.split_heads if head else self.split_residual)
 
-    def _conv3x3(self, x, x2, w, b, N, H, W_, Ho, Wo, stride=1, upsample=0, res_out=False, **kw):
+    def _with_stats(self, out, P):
+        """Attach a column-statistics buffer to a GEMM output that a GroupNorm will consume (P = rows of one frame): the
+        producing kernel's epilogue fills it (ew_gemm_args.colstats), the GroupNorm then needs no statistics pass.  Frames
+        that are not a whole number of 64-row blocks (level 3: 9 x 16) keep the stand-alone statistics kernels."""
+        if not self.fused_gn_stats or P % 64 != 0:
+            return out, None
+        hi = out.hi if isinstance(out, Res) else out
+        st = ops.colstats_alloc(hi.shape[0], hi.shape[1], hi.device)
+        if isinstance(out, Res):
+            out.stats = st
+        else:
+            out = Res(out, None, st)
+        return out, st
+
+    def _conv3x3(self, x, x2, w, b, N, H, W_, Ho, Wo, stride=1, upsample=0, res_out=False, gn_next=False, **kw):
         c1 = x.shape[-1]
         c2 = x2.shape[-1] if x2 is not None else 0
         M = N * Ho * Wo
         out = self._res(M, w.shape[0], x.device, head="r1" not in kw) if res_out else torch.empty(M, w.shape[0], dtype=torch.float16, device=x.device)
-        return ops.gemm(x, w, out, M=M, N=w.shape[0], c1=c1, lda=c1, a2=x2, c2=c2, lda2=c2, bias=b,
-                        mode=A_CONV3X3, conv=(N, H, W_, Ho, Wo, stride, upsample), **kw)
+        out, st = self._with_stats(out, Ho * Wo) if gn_next else (out, None)
+        ops.gemm(x, w, out, M=M, N=w.shape[0], c1=c1, lda=c1, a2=x2, c2=c2, lda2=c2, bias=b,
+                 mode=A_CONV3X3, conv=(N, H, W_, Ho, Wo, stride, upsample), colstats=st, **kw)
+        return out
 
-    def _convt(self, x, w, b, B, T, P, res_out=False, **kw):
+    def _convt(self, x, w, b, B, T, P, res_out=False, gn_next=False, **kw):
         C = x.shape[-1]
         M = B * T * P
         out = self._res(M, w.shape[0], x.device) if res_out else torch.empty(M, w.shape[0], dtype=torch.float16, device=x.device)
-        return ops.gemm(x, w, out, M=M, N=w.shape[0], c1=C, lda=C, bias=b, mode=A_CONVT3, tconv=(B, T, P), **kw)
+        out, st = self._with_stats(out, P) if gn_next else (out, None)
+        ops.gemm(x, w, out, M=M, N=w.shape[0], c1=C, lda=C, bias=b, mode=A_CONVT3, tconv=(B, T, P), colstats=st, **kw)
+        return out
 
     def _resblock(self, r, xs, tembs, B, T, H, W_):
         """SpatioTemporalResBlock = ResnetBlock2D -> TemporalResnetBlock -> AlphaBlender.
@@ -456,7 +476,7 @@ class UNetSpatioTemporalConditionModel:
         tb_t = tembs[:, self._temb_off[t]:]
         hN = ops.groupnorm(xs, d["n1g"], d["n1b"], N, HW, r.eps, True, pool=self._gn_pool)
         h1 = self._conv3x3(hN, None, d["c1w"], d["c1b"], N, H, W_, H, W_, rowbias=tb_s, rows_per_group=T * HW,
-                           ld_rowbias=self._temb_total)
+                           ld_rowbias=self._temb_total, gn_next=True)
         h2 = ops.groupnorm([h1], d["n2g"], d["n2b"], N, HW, r.eps, True, pool=self._gn_pool)
         if "scw" in d:
             sc = self._res(rows, r.cout, dev, head=True)
@@ -466,15 +486,15 @@ class UNetSpatioTemporalConditionModel:
                      lda2=c2, bias=d["scb"])
         else:
             sc = x1
-        xsp = self._conv3x3(h2, None, d["c2w"], d["c2b"], N, H, W_, H, W_, r1=sc, ld_r1=r.cout, res_out=True)
+        xsp = self._conv3x3(h2, None, d["c2w"], d["c2b"], N, H, W_, H, W_, r1=sc, ld_r1=r.cout, res_out=True, gn_next=True)
         g1 = ops.groupnorm([xsp], d["tn1g"], d["tn1b"], B, T * HW, r.eps, True, pool=self._gn_pool)
         t1 = self._convt(g1, d["t1w"], d["t1b"], B, T, HW, rowbias=tb_t, rows_per_group=T * HW,
-                         ld_rowbias=self._temb_total)
+                         ld_rowbias=self._temb_total, gn_next=True)
         g2 = ops.groupnorm([t1], d["tn2g"], d["tn2b"], B, T * HW, r.eps, True, pool=self._gn_pool)
         # x_temporal = xsp + conv2(..); AlphaBlender (switch_spatial_to_temporal_mix=False, the SpatioTemporalResBlock
         # default the U-Net blocks use): out = a*xsp + (1-a)*x_temporal = xsp + (1-a)*conv2(..), a = sigmoid(mix)
         return self._convt(g2, d["t2w"], d["t2b"], B, T, HW, r1=xsp, ld_r1=r.cout, c_acc=1.0 - d["mix"], c_r1=1.0,
-                           res_out=True)
+                           res_out=True, gn_next=True)
 
     def _pos_emb(self, t, B, T):
         key = (t.p, B, T)
@@ -540,7 +560,8 @@ class UNetSpatioTemporalConditionModel:
         a = d["mix"]  # AlphaBlender: a*x_spatial + (1-a)*x_temporal, x_temporal = hm + ff(..); hb is only a GEMM operand
         hb = ops.linear(ffh, d["t_f2w"], d["t_f2b"], c_acc=1.0 - a, r1=hm, ld_r1=C, c_r1=1.0 - a, r2=h, ld_r2=C, c_r2=a)
         del ffh
-        return ops.linear(hb, d["pow"], d["pob"], out=self._res(rows, C, dev), r1=x, ld_r1=C)
+        out, st = self._with_stats(self._res(rows, C, dev), S)        # feeds the next resblock's norm1 (or a skip concat)
+        return ops.linear(hb, d["pow"], d["pob"], out=out, r1=x, ld_r1=C, colstats=st)
 
     # ---------------- forward ----------------
     def forward_nhwc(self, x, timestep, encoder_hidden_states, added_time_ids, B, T, H, W_, taps=None):
@@ -565,7 +586,7 @@ class UNetSpatioTemporalConditionModel:
         ehs = encoder_hidden_states.to(device=dev, dtype=torch.float16).reshape(B, -1).contiguous()
         cvecs = ops.linear(ehs, Wt["cv_w"], Wt["cv_b"])               # all 32 cross-attention vectors at once
 
-        h = self._conv3x3(x, None, *Wt["conv_in"], N, H, W_, H, W_, res_out=True)
+        h = self._conv3x3(x, None, *Wt["conv_in"], N, H, W_, H, W_, res_out=True, gn_next=True)
         if taps is not None:
             taps["conv_in"] = (h.float(), H, W_)
         skips = [(h, H, W_)]
@@ -577,7 +598,7 @@ class UNetSpatioTemporalConditionModel:
                 skips.append((h, H, W_))
             if blk.down:
                 w, b = Wt[blk.down.p]
-                h = self._conv3x3(h.hi, None, w, b, N, H, W_, H // 2, W_ // 2, stride=2, res_out=True)
+                h = self._conv3x3(h.hi, None, w, b, N, H, W_, H // 2, W_ // 2, stride=2, res_out=True, gn_next=True)
                 H, W_ = H // 2, W_ // 2
                 skips.append((h, H, W_))
             if taps is not None:
@@ -597,7 +618,7 @@ class UNetSpatioTemporalConditionModel:
                     h = self._transformer(blk.attn[l], h, cvecs, B, T, H, W_)
             if blk.up:
                 w, b = Wt[blk.up.p]
-                h = self._conv3x3(h.hi, None, w, b, N, H, W_, 2 * H, 2 * W_, upsample=1, res_out=True)
+                h = self._conv3x3(h.hi, None, w, b, N, H, W_, 2 * H, 2 * W_, upsample=1, res_out=True, gn_next=True)
                 H, W_ = 2 * H, 2 * W_
             if taps is not None:
                 taps[f"up{bi}"] = (h.float(), H, W_)

@@ -27,7 +27,7 @@ typedef int ew_status;
 #define EW_ERR_UNSUPPORTED (-2)
 #define EW_ERR_HIP (-3)
 
-#define EW_ABI_VERSION 4
+#define EW_ABI_VERSION 5
 int ew_abi_version(void);
 const char* ew_last_error(void);
 
@@ -89,17 +89,26 @@ typedef struct ew_gemm_args {
     /* EW_A_CONV3X3 tap origin: 0 = iy = oy*stride + ky - 1 (symmetric padding 1); 1 = iy = oy*stride + ky, zero beyond the
      * bottom / right edge (F.pad(x, (0,1,0,1)) + stride-2 conv of diffusers Downsample2D(padding=0), the VAE encoder). */
     int conv_shift;
+    /* ABI 5.  Optional float [M/64][N][2]: (mean, M2) of every output column over each block of 64 consecutive output rows --
+     * the statistics a GroupNorm over this tensor needs (ew_groupnorm_finalize_colstats).  Generation-3 kernels emit them from
+     * the epilogue (no extra pass over the tensor); otherwise ew_gemm_f16 runs ew_colstats_f16 on the stored result.  Needs
+     * M % 64 == 0; not available with GEGLU.  Replaces the reference's torch.nn.GroupNorm statistics pass
+     * (diffusers ResnetBlock2D / TemporalResnetBlock norm1/norm2, evoworld/trainer/unet_plucker.py:161-233). */
+    void* colstats;
 } ew_gemm_args;
 
 ew_status ew_gemm_f16(const ew_gemm_args* args, void* stream);
-/* Kernel generation behind ew_gemm_f16: 1 = 128x160 tile, 2 blocks/CU; 2 = persistent 3-stage ring (default; env
- * EW_GEMM_GEN overrides).  Same arguments, same results to rounding; kept selectable for A/B measurements. */
+/* Kernel generation behind ew_gemm_f16: 1 = 128x160 tile, 2 blocks/CU; 2 = persistent 3-stage ring, 256x160 / 128x256 tiles;
+ * 3 (default; env EW_GEMM_GEN overrides) = persistent 256x320 (and 256x256) tile with a stream-K tail where N % 320 == 0 (or
+ * N % 256 == 0) and the problem fills the chip, generation 2 for everything else.  Same arguments, same results to rounding;
+ * kept selectable for A/B measurements. */
 void ew_set_gemm_generation(int gen);
 int ew_get_gemm_generation(void);
 /* Debug aid for measurement tools (bench.py): rocprof-style name of the kernel variant the last ew_gemm_f16 call on this
    thread's library instance launched, e.g. "gemm3_kernel<0, 8>".  Not part of the reference surface. */
 const char* ew_gemm_last_kernel(void);
-void ew_set_gemm_debug(int flags);   /* measurement-only switches (bit0: skip stores, bit1: skip epilogue, bit2: no stream-K tail); 0 = normal */
+void ew_set_gemm_debug(int flags);   /* measurement-only switches (bit0: skip stores, bit1: skip epilogue, bit2: no stream-K tail,
+                                        bit4: column statistics by the stand-alone kernel instead of the epilogue); 0 = normal */
 /* Generation 3 splits the last round of output tiles along K over its 256 persistent workgroups when whole-tile rounds would
  * leave > 4 % of the chip idle (stream-K tail: fp32 partial accumulators handed over through a library-owned uncached
  * workspace, one per (device, stream), allocated on first use: 84 MB + 67 MB for the 256-wide instance).  Deterministic: the
@@ -107,6 +116,10 @@ void ew_set_gemm_debug(int flags);   /* measurement-only switches (bit0: skip st
  * ew_gemm_streamk_status() synchronises and returns 0 when every hand-over completed, 1 if a finisher ever timed out
  * (results of that launch are invalid), -1 on a HIP error.  EW_G3_SK=0 in the environment switches the split off. */
 int ew_gemm_streamk_status(void);
+/* Allocates the stream-K workspace of (current device, stream).  Optional in eager use (the first launch that wants the tail
+ * allocates it, under a mutex); call it BEFORE capturing launches into a hipGraph -- allocation is illegal during capture, and a
+ * captured launch on a stream without a workspace runs the whole-tile schedule instead. */
+ew_status ew_gemm_streamk_init(void* stream);
 
 /* GroupNorm statistics + apply, channels-last fp16, over a (virtual) channel concat.
  * The normalised tensor has C_tot channels in `groups` groups; a stats/apply call handles the C_src channels
@@ -130,6 +143,20 @@ ew_status ew_groupnorm_finalize(float* ws, int n_slabs, int rows, int C_tot, int
 ew_status ew_groupnorm_apply_f16(const void* x, const void* x_lo, const float* ws, const void* gamma, const void* beta,
                                  void* y, int n_slabs, int rows, int C_src, int c_off, int C_tot, int groups, float eps,
                                  int silu, void* stream);
+
+/* Round 3: GroupNorm from 64-row-block column statistics (ew_gemm_args.colstats).
+ * ew_colstats_f16: stats[M/64][C][2] = (mean, M2) per channel and 64-row block of a stored tensor x [M, C] (row stride ld
+ *   elements; x_lo = optional lo8 companion) -- the stand-alone form of what the generation-3 epilogues emit.
+ * ew_groupnorm_finalize_colstats: merges blocks and channels into out[n_slabs][groups][2] = (mean, biased variance); the
+ *   normalised tensor is the channel concat of up to two sources (stats1: C1 channels, stats2: C2 channels or NULL / 0);
+ *   rows (per slab) % 64 == 0.  Deterministic (fixed reduction order), cancellation-safe.
+ * ew_groupnorm_apply_stats_f16: ew_groupnorm_apply_f16 with the (mean, variance) table given directly. */
+ew_status ew_colstats_f16(const void* x, const void* x_lo, float* stats, int M, int C, int ld, void* stream);
+ew_status ew_groupnorm_finalize_colstats(const float* stats1, int C1, const float* stats2, int C2, float* out, int n_slabs,
+                                         int rows, int groups, void* stream);
+ew_status ew_groupnorm_apply_stats_f16(const void* x, const void* x_lo, const float* stats, const void* gamma, const void* beta,
+                                       void* y, int n_slabs, int rows, int C_src, int c_off, int C_tot, int groups, float eps,
+                                       int silu, void* stream);
 
 /* LayerNorm over the last dim (fp16 in/out, fp32 two-pass statistics).  x_lo (may be NULL): lo8 companion of a split
  * residual stream (int8).  Optional fused pre-add: x' = x + addvec[row / rows_per_group][:] is what gets normalised, and x' is

@@ -108,6 +108,56 @@ __global__ __launch_bounds__(512, 2) void feed_kernel(const char* __restrict__ s
     if (t == 12345.678f) sink[tid] = t + smem[tid];
 }
 
+// ---- GEMM-like addressing: W = 320 rows (shared by every block), A = 256 rows (aliased to one row, or private per block); a
+// K-tile is the 128-byte column block kt of those rows (row stride S bytes), kt advancing along the row like the real K loop.
+template <bool ALIAS_A, int INFLIGHT>
+__global__ __launch_bounds__(512, 2) void gemm_like_kernel(const char* __restrict__ wsrc, const char* __restrict__ asrc, int S,
+                                                           int nk, int ktiles, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int srow = lane >> 3, slot = (lane & 7) ^ srow;
+    const char* ablk = asrc + (ALIAS_A ? 0 : (size_t)blockIdx.x * 256 * S);
+    int kt = (blockIdx.x * 7) % nk;
+    for (int v = 0; v < ktiles; ++v) {
+        char* buf = smem + (v & 1) * 73728;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = ALIAS_A ? 0 : (wave + 8 * i) * 8 + srow;
+            __builtin_amdgcn_global_load_lds((gptr_t)(ablk + (size_t)row * S + kt * 128 + slot * 16), (lptr_t)(buf + (wave + 8 * i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int row = (wave + 8 * j) * 8 + srow;
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)row * S + kt * 128 + slot * 16), (lptr_t)(buf + 32768 + (wave + 8 * j) * 1024), 16, 0, 0);
+        }
+        if constexpr (INFLIGHT == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (++kt == nk) kt = 0;
+    }
+    if (ktiles == -1) sink[tid] = smem[tid];
+}
+
+template <bool ALIAS_A, int INFLIGHT>
+void run_gemm_like(const char* wsrc, const char* asrc, int S, float* sink, const char* label) {
+    const int ktiles = 4000, nk = S / 128;
+    const size_t lds = 2 * 73728;
+    CK(hipFuncSetAttribute((const void*)gemm_like_kernel<ALIAS_A, INFLIGHT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((gemm_like_kernel<ALIAS_A, INFLIGHT>), dim3(256), dim3(512), lds, 0, wsrc, asrc, S, nk, ktiles, sink);
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, a, b));
+        if (rep == 2) printf("gemm-like S=%5d %-12s in flight %d: %-40s %8.3f ms  %7.1f GB/s per CU\n", S, ALIAS_A ? "A aliased" : "A private", INFLIGHT, label, ms,
+                        73728.0 * ktiles / ms / 1e6);
+    }
+}
+
 template <int MODE>
 void run(const char* src, float* sink, const char* label, double bytes_per_tile) {
     const int ktiles = 4000;
@@ -141,5 +191,17 @@ int main() {
     run<2>(src, sink, "all VGPR loads, 8 rows x 128 B per instr", 73728);
     run<3>(src, sink, "A 32 KB LDS-DMA + W 40 KB VGPR contiguous (1x per block)", 73728);
     run<4>(src, sink, "A 32 KB LDS-DMA + W VGPR, each wave its N half (4x redundant)", 32768 + 8 * 20480);
+    char* big;
+    const size_t big_bytes = (size_t)256 * 256 * 10496 + (size_t)320 * 10496 + 65536;
+    CK(hipMalloc(&big, big_bytes));
+    CK(hipMemset(big, 0x3c, big_bytes));
+    for (int S : {2560, 5120, 10240, 10368}) {
+        const char* w = big;
+        const char* a = big + (size_t)320 * 10496;
+        run_gemm_like<true, 1>(w, a, S, sink, "W 320 rows shared, A one line");
+        run_gemm_like<true, 2>(w, a, S, sink, "W 320 rows shared, A one line");
+        run_gemm_like<false, 1>(w, a, S, sink, "W shared, A 256 private rows per block");
+        run_gemm_like<false, 2>(w, a, S, sink, "W shared, A 256 private rows per block");
+    }
     return 0;
 }
