@@ -24,15 +24,34 @@ ALGO_TFLOP_PER_FORWARD = 154.31      # SURVEY.md §8d, config 2, dead cross-atte
 PEAK_F16_DENSE_TFLOPS = 2500.0       # MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16 MFMA
 
 
-def committed_traffic():
-    """HBM bytes of ONE U-Net forward from the committed rocprofv3 PMC run (profiles/r02_hbm_traffic.json: separate
+def source_fingerprint():
+    """sha256 over the kernel sources and the files that decide which kernels a forward launches: a recorded PMC measurement is
+    only attached to the bench line when it was taken on exactly this code."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "evoworld_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "evoworld_amd", "csrc", "*.h")))
+    files += [os.path.join(ROOT, "evoworld_amd", f) for f in ("unet.py", "ops.py")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(residual_mode):
+    """HBM bytes of ONE U-Net forward from the committed rocprofv3 PMC run (profiles/r03_hbm_traffic.json: separate
     --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.sh).
-    It is a recorded measurement of this code, not a live one: PMC collection needs its own profiler passes."""
-    f = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    PMC collection needs its own profiler passes, so this is a RECORDED measurement: it carries the fingerprint of the sources
+    and the residual-stream mode it was taken on, and is reported as stale (traffic = null in the bench line) when either
+    differs from what is running."""
+    f = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
     try:
-        return json.load(open(f))
+        tr = json.load(open(f))
     except (OSError, ValueError):
         return None
+    rec = tr.get("recorded_at", {})
+    tr["stale"] = not (rec.get("source_fingerprint") == source_fingerprint() and rec.get("residual_stream") == residual_mode)
+    return tr
 
 
 def synth_inputs(T, h, w, seed, device):
@@ -55,8 +74,9 @@ def synth_inputs(T, h, w, seed, device):
 def cpu_baseline(max_threads=32, frames=4):
     """The reference's CPU path (diffusers fp32 on PyTorch) restated by the oracle, timed on the host cores on a
     BOUNDED sample (~15-20 s of CPU work): one full-resolution (72x128 latents) U-Net forward over `frames` frames of ONE CFG
-    row (B=1, T=4, so the temporal convs / temporal attention see more than one frame), incl. the reference's dead
-    cross-attention work, scaled linearly to a clip step (B=2, T=25 = 50 frames).  The extrapolation error was measured once
+    row (B=1, T=`frames` -- 4 by default, so the temporal convs / temporal attention see more than one frame; frames >= 50 runs
+    the complete B=2, T=25 forward instead), incl. the reference's dead cross-attention work, scaled linearly to a clip step
+    (B=2, T=25 = 50 frames).  A one-frame forward runs first, untimed (thread pool, allocator and weight pages warm).  The extrapolation error was measured once
     against a COMPLETE full-size CPU forward (`bench.py --cpu-baseline-full`).  `cores` = the threads
     used (torch's CPU convs do not scale past a few dozen threads on this problem: 256 threads measured 20x slower than 32);
     `host_cores` = os.cpu_count()."""
@@ -80,6 +100,7 @@ def cpu_baseline(max_threads=32, frames=4):
     x = torch.randn(B, TS, 18, 72, 128, generator=g)
     ehs = torch.randn(B, 1, 1024, generator=g)
     ids = torch.tensor([[6.0, 127.0, 0.02]] * B)
+    m(x[:1, :1], torch.tensor(1.0), ehs[:1], ids[:1], exec_dead_cross_attn=True)          # untimed warm-up
     t0 = time.time()
     m(x, torch.tensor(1.0), ehs, ids, exec_dead_cross_attn=True)
     dt = time.time() - t0
@@ -300,6 +321,8 @@ def main():
     dt = D.max_over_ranks(dt, dev)
     unet.forward_nhwc = orig_forward
     finite = all(bool(torch.isfinite(r).all()) for r in res)
+    from evoworld_amd import ops as _ops
+    _ops.streamk_check()                      # (pipe.denoise already checked after every clip; this covers the hooked forward too)
 
     kernels = kernel_breakdown(unet, pipe, latents, image_latents, ehs, plucker, T, h, w) if rank == 0 else None
     fp16_ms = fp16_stream_forward_ms(unet, ehs, T, h, w) if rank == 0 and unet.split_residual and not args.no_fp16_stream else None
@@ -308,7 +331,7 @@ def main():
         fw_ms = sum(s.elapsed_time(e) for s, e in fw_events) / max(1, len(fw_events))
         full = (not args.tiny) and (T, args.height, args.width, args.denoise_steps) == (25, 576, 1024, 25)
         ach = ALGO_TFLOP_PER_FORWARD / (fw_ms / 1e3) if full else None
-        tr = committed_traffic()
+        tr = committed_traffic("split" if unet.split_residual else "fp16")
         line = {
             "metric": "panoramic frames/sec per clip (576x1024x25f, 25 denoise steps)",
             "value": world * T * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -321,7 +344,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "U-Net denoise step (all launches of one forward, HIP events on the launch stream)",
                          "achieved": ach, "peak": PEAK_F16_DENSE_TFLOPS, "unit": "TFLOP/s",
                          "frac": (ach / PEAK_F16_DENSE_TFLOPS) if ach else None,
-                         "traffic": (tr or {}).get("bytes_per_forward") if full else None, "traffic_detail": tr,
+                         "traffic": (tr or {}).get("bytes_per_forward") if full and tr and not tr["stale"] else None, "traffic_detail": tr,
                          "algorithmic_tflop_per_launch": ALGO_TFLOP_PER_FORWARD,
                          "kernels": kernels},
         }

@@ -81,13 +81,9 @@ __device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, in
     tn = k * band + (r - tm * w);
 }
 
-// EPIX = epilogue mask (bit 0 row-bias, 1 r1, 2 r2, 3 GEGLU, 4 lo8 companions) | 32: also emit per-64-row-block column statistics
-// of the result (p.colstats: what the GroupNorm that consumes this tensor needs; replaces a separate pass over the tensor).
-template <int MODE, int EPIX>
+template <int MODE, int EPI>
 __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const SkP sk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int EPI = EPIX & 31;
-    constexpr bool STATS = (EPIX & 32) != 0;
     // epilogue family: GEGLU (EPI & 8) and the conv modes without lo8 operands go through a wave-private LDS patch; dense GEMMs
     // and everything that carries the split residual stream use the LDS-free direct epilogue (permuted W staging)
     constexpr bool DIRECT = (EPI & 8) == 0 && (MODE == EW_A_DENSE || (EPI & 16));
@@ -403,16 +399,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                     f16* patch16 = (f16*)patch;
                     const int rpg = p.rows_per_group;
                     const bool silu = p.act == EW_ACT_SILU, gelu = MODE == EW_A_DENSE && EPI == 0 && p.act == EW_ACT_GELU;
-                    // column statistics (STATS): the passes run half-major (h outer) so that only one half's accumulators are live
-                    float cs_s[2] = {}, cs_q[2] = {}, cs_p[2] = {};
-                    constexpr int N_OUT = STATS ? NH : FM, N_IN = STATS ? FM : NH;
 #pragma unroll
-                    for (int lo_ = 0; lo_ < N_OUT; ++lo_) {
+                    for (int i = 0; i < FM; ++i) {
+                        const int m_l = min(m_w0 + i * 16 + frow, p.M - 1);
+                        const int g = RB ? m_l / rpg : 0;
 #pragma unroll
-                        for (int li_ = 0; li_ < N_IN; ++li_) {
-                            const int i = STATS ? li_ : lo_, h = STATS ? lo_ : li_;
-                            const int m_l = min(m_w0 + i * 16 + frow, p.M - 1);
-                            const int g = RB ? m_l / rpg : 0;
+                        for (int h = 0; h < NH; ++h) {
 #pragma unroll
                             for (int jj = 0; jj < CP / 16; ++jj) {
                                 const int j = h * (CP / 16) + jj;
@@ -435,31 +427,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                                 *(f16x4*)(patch16 + frow * LDH + jj * 16 + fks * 4) = o4;
                             }
                             __builtin_amdgcn_wave_barrier();
-                            if constexpr (STATS) {
-                                // column statistics of the 16 x CP fp16 values just written (= what is stored): lane L < CP/2 owns the
-                                // column pair 2L, 2L+1 of this half; shifted sums with the pivot = the column's first row of the wave tile
-                                if (lane < CP / 2) {
-#pragma unroll
-                                    for (int r = 0; r < 16; ++r) {
-                                        const f16x2 v2 = *(const f16x2*)(patch16 + r * LDH + 2 * lane);
-                                        const float x0 = (float)v2[0], x1 = (float)v2[1];
-                                        if (i == 0 && r == 0) { cs_p[0] = x0; cs_p[1] = x1; cs_s[0] = cs_s[1] = cs_q[0] = cs_q[1] = 0.f; }
-                                        const float d0 = x0 - cs_p[0], d1 = x1 - cs_p[1];
-                                        cs_s[0] += d0; cs_q[0] = fmaf(d0, d0, cs_q[0]);
-                                        cs_s[1] += d1; cs_q[1] = fmaf(d1, d1, cs_q[1]);
-                                    }
-                                    if (i == FM - 1 && m_w0 < p.M) {     // M % 64 == 0 (launcher): a wave tile is all rows or none
-                                        f32x4 st;
-#pragma unroll
-                                        for (int c = 0; c < 2; ++c) {
-                                            const float d = cs_s[c] * (1.0f / WM);
-                                            st[2 * c] = cs_p[c] + d;                                   // mean over the 64 rows
-                                            st[2 * c + 1] = fmaxf(fmaf(-cs_s[c], d, cs_q[c]), 0.f);    // M2
-                                        }
-                                        *(f32x4*)(p.colstats + ((size_t)(m_w0 / WM) * p.N + n_w0 + h * CP + 2 * lane) * 2) = st;
-                                    }
-                                }
-                            }
 #pragma unroll
                             for (int it = 0; it < ITERS; ++it) {
                                 const int idx = it * 64 + lane;
@@ -582,43 +549,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                         if constexpr (R2 && LO) q2l = *(const u32x2*)((const char*)r2lp + (unsigned)(mc * ld2l + n * m2l));
                     };
                     const bool silu = p.act == EW_ACT_SILU, gelu = MODE == EW_A_DENSE && EPI == 0 && p.act == EW_ACT_GELU;
-                    // Column statistics (STATS): the fp32 results of a step (16 rows x 32 columns) go through a wave-private
-                    // 16 x 36-float patch; lane L owns column L & 31 over the rows 8 * (L >> 5) ... + 7 of every 16-row fragment
-                    // and reads them back ONE STEP LATER (LDS operations of a wave complete in issue order, so the single
-                    // buffer is safe and the read latency is covered by the next step's operand arithmetic).
-                    // With STATS the steps run column-block-major (q outer, i inner): one column block's accumulators are live at a
-                    // time (3 registers instead of 15 -- the row-major order spilled ~130 VGPRs per lane here).
-                    constexpr int SLD = 36;
-                    float cs_s = 0.f, cs_q = 0.f, cs_p = 0.f;
-                    float cs_rd[8];
-                    const float* cs_rp = patch + ((lane >> 5) * 8) * SLD + (lane & 31);
-                    auto cs_accumulate = [&](int ip, int qp) __attribute__((always_inline)) {   // consume the values read at the previous step
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            if (ip == 0 && r == 0) { cs_p = cs_rd[0]; cs_s = 0.f; cs_q = 0.f; }
-                            const float d = cs_rd[r] - cs_p;
-                            cs_s += d;
-                            cs_q = fmaf(d, d, cs_q);
-                        }
-                        if (ip == FM - 1) {
-                            // a lane holds 32 rows (8 of each fragment) of its column; its partner L ^ 32 the other 32: equal-count merge
-                            const float d = cs_s * (1.0f / 32.0f);
-                            const float mean = cs_p + d;
-                            const float m2 = fmaxf(fmaf(-cs_s, d, cs_q), 0.f);
-                            const float mean_o = __shfl_xor(mean, 32, 64), m2_o = __shfl_xor(m2, 32, 64);
-                            const float dm = mean - mean_o;
-                            const f32x2 st = {0.5f * (mean + mean_o), m2 + m2_o + 16.0f * dm * dm};
-                            if (lane < 32 && m_w0 < p.M)          // M % 64 == 0 (launcher): a wave tile is all rows or none
-                                *(f32x2*)(p.colstats + ((size_t)(m_w0 / WM) * p.N + n_w0 + qp * 32 + lane) * 2) = st;
-                        }
-                    };
-                    constexpr int N_OUT = STATS ? NQ : FM, N_IN = STATS ? FM : NQ;
                     fetch(0, 0);
 #pragma unroll
-                    for (int lo_ = 0; lo_ < N_OUT; ++lo_) {
+                    for (int i = 0; i < FM; ++i) {
 #pragma unroll
-                        for (int li_ = 0; li_ < N_IN; ++li_) {
-                            const int i = STATS ? li_ : lo_, q = STATS ? lo_ : li_;
+                        for (int q = 0; q < NQ; ++q) {
                             const int m = m_w0 + i * 16 + frow, n = ncol0 + q * 32;
                             const f32x4 a0 = acc[i][2 * q], a1 = acc[i][2 * q + 1];
                             float vv[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
@@ -646,27 +581,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                                 else if constexpr (R2) x += p.c_r2 * (float)q2v[e];
                                 o[e] = (f16)x;
                                 if constexpr (LO) s8[e] = ew_split_enc(x, o[e]);
-                                if constexpr (STATS) vv[e] = LO ? x : (float)o[e];       // the value as stored (fp32 of the split pair ~ x)
                             }
                             if constexpr (LO) { ol[0] = ew_pack4(s8[0], s8[1], s8[2], s8[3]); ol[1] = ew_pack4(s8[4], s8[5], s8[6], s8[7]); }
-                            if constexpr (STATS) {
-                                if (i + q > 0) cs_accumulate(i == 0 ? FM - 1 : i - 1, i == 0 ? q - 1 : q);
-                                float* pw = patch + frow * SLD + fks * 8;
-                                *(f32x4*)pw = (f32x4){vv[0], vv[1], vv[2], vv[3]};
-                                *(f32x4*)(pw + 4) = (f32x4){vv[4], vv[5], vv[6], vv[7]};
-                                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                                for (int r = 0; r < 8; ++r) cs_rd[r] = cs_rp[r * SLD];
-                                __builtin_amdgcn_wave_barrier();
-                            }
                             __builtin_amdgcn_sched_barrier(0);
-                            if constexpr (STATS) {
-                                if (i + 1 < FM) fetch(i + 1, q);
-                                else if (q + 1 < NQ) fetch(0, q + 1);
-                            } else {
-                                if (q + 1 < NQ) fetch(i, q + 1);
-                                else if (i + 1 < FM) fetch(i + 1, 0);
-                            }
+                            if (q + 1 < NQ) fetch(i, q + 1);
+                            else if (i + 1 < FM) fetch(i + 1, 0);
                             __builtin_amdgcn_sched_barrier(0);
                             if ((FULL || m < p.M) && !(p.dbg & 1)) {
                                 *(f16x8*)((char*)p.out + (unsigned)(m * p.ld_out + n) * 2u) = o;
@@ -676,7 +595,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                             }
                         }
                     }
-                    if constexpr (STATS) cs_accumulate(FM - 1, NQ - 1);
                 } else {
                     // GEGLU: staged column blocks of 32 = [16 value | 16 gate] -> fragment 2q holds the values, 2q+1 the gates of
                     // the SAME (row, column) positions in the SAME lane: value*gelu(gate) in registers, WN/2 = 80 output columns
@@ -900,7 +818,7 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
     // GEMMs with at most two tile columns and K >= 1280 (-4 ... -8 %).  With four tile columns (level 2) the blocks of an XCD
     // are out of phase along K and stop sharing the A rows and W slices in L2: +7 ... +16 % -- left on the whole-tile schedule.
     const bool sk_shape = MODE == EW_A_CONV3X3 || (q.tiles_n <= 2 && p.K >= sk_min_k) || sk_mode == 2;
-    if (sk_mode && sk_shape && !(MODE == EW_A_DENSE && (EPI & 31) == 23) && !(p.dbg & 4) && grid == 256 && tiles > 256 && tiles % 256 != 0) {
+    if (sk_mode && sk_shape && !(MODE == EW_A_DENSE && EPI == 23) && !(p.dbg & 4) && grid == 256 && tiles > 256 && tiles % 256 != 0) {
         const long long rounds = (tiles + 255) / 256;
         const double loss = 1.0 - (double)tiles / (256.0 * rounds);
         if (loss > 0.04) {
@@ -919,14 +837,9 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
     return ew_check_launch("ew_gemm_f16(gen3)");
 }
 
-// operand sets that occur in the U-Net (evoworld_amd/unet.py); any other mask runs on the smallest compiled superset.
-// p.colstats (column statistics for the consuming GroupNorm) is emitted in the epilogue by the variants that produce GroupNorm
-// inputs in the U-Net -- dense / conv with r1 + split output (<.,19>, <.,18>) and conv + row-bias with a plain fp16 output
-// (<.,1>) -- when M % 64 == 0; *stats_done tells the caller (ew_gemm_f16) whether it still has to run the stand-alone kernel.
+// operand sets that occur in the U-Net (evoworld_amd/unet.py); any other mask runs on the smallest compiled superset
 template <int MODE>
-ew_status dispatch_epi3(const GemmP& p, hipStream_t s, bool* stats_done) {
-    const bool want_stats = p.colstats != nullptr && p.M % WM == 0 && !(p.dbg & 16);      // dbg bit 4: A/B switch (stand-alone statistics kernel)
-    *stats_done = false;
+ew_status dispatch_epi3(const GemmP& p, hipStream_t s) {
     if (p.act == EW_ACT_GEGLU) {
         if constexpr (MODE == EW_A_DENSE) return launch3<MODE, 8>(p, s);
         else { ew_set_error("ew_gemm_f16: GEGLU epilogue is only built for dense mode"); return EW_ERR_UNSUPPORTED; }
@@ -934,27 +847,16 @@ ew_status dispatch_epi3(const GemmP& p, hipStream_t s, bool* stats_done) {
     const int mask = (p.rowbias ? 1 : 0) | (p.r1 ? 2 : 0) | (p.r2 ? 4 : 0);
     if (p.r1_lo || p.r2_lo || p.out_lo) {           // split-fp16 residual stream: general path with the lo companions
         if constexpr (MODE == EW_A_DENSE) {
-            if ((mask & 4) == 0) {
-                if (want_stats) { *stats_done = true; return launch3<MODE, 32 | 16 | 3>(p, s); }
-                return launch3<MODE, 16 | 3>(p, s);
-            }
+            if ((mask & 4) == 0) return launch3<MODE, 16 | 3>(p, s);
             return launch3<MODE, 16 | 7>(p, s);
         } else {
-            if ((mask & 5) == 0) {
-                if (want_stats) { *stats_done = true; return launch3<MODE, 32 | 16 | 2>(p, s); }
-                return launch3<MODE, 16 | 2>(p, s);
-            }
+            if ((mask & 5) == 0) return launch3<MODE, 16 | 2>(p, s);
             ew_set_error("ew_gemm_f16: conv modes carry the split residual only with r1 (no row-bias / r2)");
             return EW_ERR_UNSUPPORTED;
         }
     }
     if (mask == 0) return launch3<MODE, 0>(p, s);
-    if (mask == 1) {
-        if constexpr (MODE != EW_A_DENSE) {
-            if (want_stats) { *stats_done = true; return launch3<MODE, 32 | 1>(p, s); }
-        }
-        return launch3<MODE, 1>(p, s);
-    }
+    if (mask == 1) return launch3<MODE, 1>(p, s);
     if (mask == 2) return launch3<MODE, 2>(p, s);
     if constexpr (MODE == EW_A_DENSE) {
         if (mask == 3) return launch3<MODE, 3>(p, s);
@@ -985,8 +887,8 @@ bool EW3_NAME(ew_gemm3_wants)(const GemmP& p) {
     return tiles >= 200;
 }
 
-ew_status EW3_NAME(ew_gemm3_dispatch)(const GemmP& p, hipStream_t s, bool* stats_done) {
-    if (p.mode == EW_A_CONV3X3) return dispatch_epi3<EW_A_CONV3X3>(p, s, stats_done);
-    if (p.mode == EW_A_CONVT3) return dispatch_epi3<EW_A_CONVT3>(p, s, stats_done);
-    return dispatch_epi3<EW_A_DENSE>(p, s, stats_done);
+ew_status EW3_NAME(ew_gemm3_dispatch)(const GemmP& p, hipStream_t s) {
+    if (p.mode == EW_A_CONV3X3) return dispatch_epi3<EW_A_CONV3X3>(p, s);
+    if (p.mode == EW_A_CONVT3) return dispatch_epi3<EW_A_CONVT3>(p, s);
+    return dispatch_epi3<EW_A_DENSE>(p, s);
 }

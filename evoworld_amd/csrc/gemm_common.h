@@ -15,7 +15,6 @@ struct GemmP {
     const int8_t* r1_lo;   // split residual stream: lo8 companions, one byte per element, same element strides (may be null)
     const int8_t* r2_lo;
     int8_t* out_lo;
-    float* colstats;       // optional [M/64][N][2]: (mean, M2) of every output column over each 64-row block (generation 3, EPI | 32)
     int M, N, K;
     int c1, c2, lda, lda2, ld_out, ld_r1, ld_r2, ld_rowbias;
     int mode, n_img, h_in, w_in, h_out, w_out, stride, upsample;

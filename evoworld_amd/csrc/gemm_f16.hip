@@ -279,10 +279,9 @@ ew_status launch(const GemmP& p, hipStream_t s) {
 }  // namespace
 
 ew_status ew_gemm2_dispatch(const GemmP& p, hipStream_t s);   // gemm2_f16.hip
-ew_status ew_gemm3_dispatch(const GemmP& p, hipStream_t s, bool* stats_done);   // gemm3_f16.hip
-ew_status ew_colstats_launch(const f16* x, const int8_t* x_lo, float* stats, int M, int C, int ld, hipStream_t s);   // norm.hip
+ew_status ew_gemm3_dispatch(const GemmP& p, hipStream_t s);   // gemm3_f16.hip
 bool ew_gemm3_wants(const GemmP& p);
-ew_status ew_gemm3_dispatch_b256(const GemmP& p, hipStream_t s, bool* stats_done);   // gemm3_f16.hip compiled with EW3_BN=256
+ew_status ew_gemm3_dispatch_b256(const GemmP& p, hipStream_t s);   // gemm3_f16.hip compiled with EW3_BN=256
 bool ew_gemm3_wants_b256(const GemmP& p);
 static int g_gemm_gen = -1;
 char g_gemm_last_kernel[64] = "";          // rocprof-style name of the kernel the last ew_gemm_f16 call launched
@@ -337,8 +336,6 @@ extern "C" ew_status ew_gemm_f16(const ew_gemm_args* a, void* stream) {
     p.zero_page = (const f16*)a->zero_page;
     p.r1_lo = (const int8_t*)a->r1_lo; p.r2_lo = (const int8_t*)a->r2_lo; p.out_lo = (int8_t*)a->out_lo;
     p.conv_shift = a->conv_shift;
-    p.colstats = (float*)a->colstats;
-    EW_REQUIRE(!a->colstats || (a->act != EW_ACT_GEGLU && a->M % 64 == 0 && a->N % 8 == 0), "ew_gemm_f16: colstats needs M %% 64 == 0, N %% 8 == 0, no GEGLU");
     p.M = a->M; p.N = a->N; p.K = taps * (a->c1 + a->c2);
     p.c1 = a->c1; p.c2 = a->c2; p.lda = a->lda; p.lda2 = a->lda2; p.ld_out = a->ld_out; p.ld_r1 = a->ld_r1; p.ld_r2 = a->ld_r2; p.ld_rowbias = a->ld_rowbias;
     p.mode = a->mode; p.n_img = a->n_img; p.h_in = a->h_in; p.w_in = a->w_in; p.h_out = a->h_out; p.w_out = a->w_out;
@@ -349,15 +346,11 @@ extern "C" ew_status ew_gemm_f16(const ew_gemm_args* a, void* stream) {
     p.dbg = g_gemm_dbg;
     hipStream_t s = (hipStream_t)stream;
     // generation 3 (256x320 tile) where it applies and fills the chip, generation 2 otherwise
-    bool stats_done = false;
-    ew_status st;
-    if (ew_get_gemm_generation() >= 3 && ew_gemm3_wants(p)) st = ew_gemm3_dispatch(p, s, &stats_done);
-    else if (ew_get_gemm_generation() >= 3 && ew_gemm3_wants_b256(p)) st = ew_gemm3_dispatch_b256(p, s, &stats_done);
-    else if (ew_get_gemm_generation() >= 2) st = ew_gemm2_dispatch(p, s);
+    if (ew_get_gemm_generation() >= 3 && ew_gemm3_wants(p)) return ew_gemm3_dispatch(p, s);
+    if (ew_get_gemm_generation() >= 3 && ew_gemm3_wants_b256(p)) return ew_gemm3_dispatch_b256(p, s);
+    if (ew_get_gemm_generation() >= 2) return ew_gemm2_dispatch(p, s);
     // generation 1 tile choice: every channel count of the U-Net is a multiple of 160 (320*k); GEGLU and odd sizes use 128
-    else if (a->act != EW_ACT_GEGLU && a->N % 160 == 0) { snprintf(g_gemm_last_kernel, 64, "gemm_kernel<128, 160>"); st = launch<128, 160>(p, s); }
-    else { snprintf(g_gemm_last_kernel, 64, "gemm_kernel<128, 128>"); st = launch<128, 128>(p, s); }
-    // column statistics the kernel did not emit in its epilogue: one pass over the stored result (same format, same consumer)
-    if (st == EW_OK && p.colstats && !stats_done) st = ew_colstats_launch(p.out, p.out_lo, p.colstats, p.M, p.N, p.ld_out, s);
-    return st;
+    if (a->act != EW_ACT_GEGLU && a->N % 160 == 0) { snprintf(g_gemm_last_kernel, 64, "gemm_kernel<128, 160>"); return launch<128, 160>(p, s); }
+    snprintf(g_gemm_last_kernel, 64, "gemm_kernel<128, 128>");
+    return launch<128, 128>(p, s);
 }

@@ -178,128 +178,6 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     if (tid == 0) *(f32x2*)(stats + (size_t)blockIdx.x * 2) = (f32x2){mean, (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (n * (float)gs)};
 }
 
-// ---------------------------------------------------------------------------------------------
-// Column statistics in 64-row blocks (round 3): stats[M/64][C][2] = (mean, M2) of every channel over each block of 64
-// consecutive rows.  This is the format the generation-3 GEMM epilogues emit for the tensor they produce (gemm3_f16.hip,
-// EPI | 32), which removes the statistics pass over it; colstats_kernel computes the same thing from a stored tensor
-// (producers on other kernel generations, tensors that do not come from a GEMM).  A GroupNorm slab (a frame of H*W rows, or
-// the T frames of a batch element for the temporal blocks) is a whole number of 64-row blocks at levels 0-2 of the U-Net.
-// gn_finalize_colstats_kernel merges blocks and channels (equal counts: mean = average of means, M2 = sum M2 + 64 * sum (mean_i -
-// mean)^2) in a fixed order -- deterministic, no atomics, cancellation-safe (every partial is centred on its own mean).
-// ---------------------------------------------------------------------------------------------
-__global__ void colstats_kernel(const f16* __restrict__ x, const int8_t* __restrict__ x_lo, float* __restrict__ stats, int C,
-                                int ld, int VPP, int PL) {
-    extern __shared__ float lds[];  // [PL][2][C]
-    const int tid = threadIdx.x;
-    const int v = tid % VPP, pl = tid / VPP;
-    const size_t base_off = (size_t)blockIdx.x * 64 * ld + v * 8;
-    const f16* base = x + base_off;
-    const int8_t* base_lo = x_lo ? x_lo + base_off : nullptr;
-    float s[8], q[8], piv[8];
-    {
-        const f16x8 p0 = *(const f16x8*)base;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; piv[e] = (float)p0[e]; }
-        if (base_lo) ew_split_dec8(p0, *(const u32x2*)base_lo, piv);
-    }
-    for (int r = pl; r < 64; r += PL) {
-        const f16x8 val = *(const f16x8*)(base + (size_t)r * ld);
-        float xv[8];
-        if (base_lo) ew_split_dec8(val, *(const u32x2*)(base_lo + (size_t)r * ld), xv);
-        else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) xv[e] = (float)val[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float f = xv[e] - piv[e];
-            s[e] += f;
-            q[e] = fmaf(f, f, q[e]);
-        }
-    }
-    float* mine = lds + (size_t)pl * 2 * C;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        mine[v * 8 + e] = s[e];
-        mine[C + v * 8 + e] = q[e];
-    }
-    __syncthreads();
-    if (pl == 0) {
-        f32x2 out[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float ss = 0.f, qq = 0.f;
-            for (int k = 0; k < PL; ++k) { ss += lds[(size_t)k * 2 * C + v * 8 + e]; qq += lds[(size_t)k * 2 * C + C + v * 8 + e]; }
-            const float d = ss * (1.0f / 64.0f);
-            out[e] = (f32x2){piv[e] + d, fmaxf(fmaf(-ss, d, qq), 0.f)};
-        }
-        float* dst = stats + ((size_t)blockIdx.x * C + v * 8) * 2;
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) *(f32x4*)(dst + 2 * e) = (f32x4){out[e][0], out[e][1], out[e + 1][0], out[e + 1][1]};
-    }
-}
-
-// one 256-thread block per (slab, group).  Element k of the group = (row block b, channel c) in the fixed order k = b * gs + c;
-// thread t takes k = t, t + 256, ...; block reductions through LDS in a fixed tree.  Channels of a virtual concat come from two
-// statistics arrays (st1: channels [0, C1), st2: [C1, C1 + C2)).
-__global__ __launch_bounds__(256) void gn_finalize_colstats_kernel(const float* __restrict__ st1, int C1, const float* __restrict__ st2,
-                                                                   int C2, float* __restrict__ out, int rows, int groups) {
-    __shared__ float red[256];
-    const int tid = threadIdx.x;
-    const int slab = blockIdx.x / groups, g = blockIdx.x - slab * groups;
-    const int C_tot = C1 + C2, gs = C_tot / groups;
-    const int nb = rows / 64;
-    const int n_el = nb * gs;
-    auto elem = [&](int k) -> const float* {
-        const int b = k / gs, c = g * gs + (k - b * gs);
-        const size_t blk = (size_t)slab * nb + b;
-        return c < C1 ? st1 + (blk * C1 + c) * 2 : st2 + (blk * C2 + (c - C1)) * 2;
-    };
-    auto block_sum = [&](float v) {
-        red[tid] = v;
-        __syncthreads();
-#pragma unroll
-        for (int o = 128; o > 0; o >>= 1) {
-            if (tid < o) red[tid] += red[tid + o];
-            __syncthreads();
-        }
-        const float r = red[0];
-        __syncthreads();
-        return r;
-    };
-    // one pass, shifted by the pivot P = the first block mean of the group (a real sample, so |mean_i - P| ~ the spread):
-    // a = sum(mean_i - P), b = sum((mean_i - P)^2), c = sum(M2_i)  ->  mean = P + a/n, M2 = c + 64 * (b - a^2/n)
-    const float P = elem(0)[0];
-    float a = 0.f, b = 0.f, c = 0.f;
-    int k = tid;
-    for (; k + 3 * 256 < n_el; k += 4 * 256) {                 // four independent loads in flight
-        f32x2 e[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = *(const f32x2*)elem(k + u * 256);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float d = e[u][0] - P;
-            a += d;
-            b = fmaf(d, d, b);
-            c += e[u][1];
-        }
-    }
-    for (; k < n_el; k += 256) {
-        const f32x2 e = *(const f32x2*)elem(k);
-        const float d = e[0] - P;
-        a += d;
-        b = fmaf(d, d, b);
-        c += e[1];
-    }
-    const float A = block_sum(a), B = block_sum(b), Cc = block_sum(c);
-    if (tid == 0) {
-        const float n = (float)n_el;
-        const float dm = A / n;
-        const float M2 = Cc + 64.0f * fmaxf(B - A * dm, 0.f);
-        *(f32x2*)(out + (size_t)blockIdx.x * 2) = (f32x2){P + dm, M2 / ((float)rows * (float)gs)};
-    }
-}
-
 // GroupNorm apply (+SiLU).  Same thread layout as the statistics kernel: grid = (row chunks, n_slabs), block = PL * VPP
 // threads, every thread owns one fixed 8-channel vector of one slab -> mean / rstd / gamma / beta collapse ONCE per thread
 // into scale[8], shift[8]; the row loop is load, 8 fma (+SiLU), store.  (The first version re-derived (row, column, slab,
@@ -530,56 +408,10 @@ extern "C" ew_status ew_groupnorm_finalize(float* ws, int n_slabs, int rows, int
     return ew_check_launch("ew_groupnorm_finalize");
 }
 
-static ew_status gn_apply_launch(const void* x, const void* x_lo, const float* stats, const void* gamma,
-                                 const void* beta, void* y, int n_slabs, int rows, int C_src, int c_off, int C_tot,
-                                 int groups, float eps, int silu, void* stream);
-
 extern "C" ew_status ew_groupnorm_apply_f16(const void* x, const void* x_lo, const float* ws, const void* gamma,
                                             const void* beta, void* y, int n_slabs, int rows, int C_src, int c_off, int C_tot,
                                             int groups, float eps, int silu, void* stream) {
-    EW_REQUIRE(ws, "ew_groupnorm_apply_f16: null pointer");
-    EW_REQUIRE(n_slabs > 0 && rows > 0 && C_tot > 0, "ew_groupnorm_apply_f16: bad shape");
-    return gn_apply_launch(x, x_lo, gn_ws((float*)ws, n_slabs, rows, C_tot).stats, gamma, beta, y, n_slabs, rows, C_src, c_off, C_tot,
-                           groups, eps, silu, stream);
-}
-
-extern "C" ew_status ew_groupnorm_apply_stats_f16(const void* x, const void* x_lo, const float* stats, const void* gamma,
-                                                  const void* beta, void* y, int n_slabs, int rows, int C_src, int c_off,
-                                                  int C_tot, int groups, float eps, int silu, void* stream) {
-    return gn_apply_launch(x, x_lo, stats, gamma, beta, y, n_slabs, rows, C_src, c_off, C_tot, groups, eps, silu, stream);
-}
-
-ew_status ew_colstats_launch(const f16* x, const int8_t* x_lo, float* stats, int M, int C, int ld, hipStream_t s) {
-    EW_REQUIRE(x && stats, "ew_colstats_f16: null pointer");
-    EW_REQUIRE(M > 0 && M % 64 == 0 && C > 0 && C % 8 == 0 && ld >= C && ld % 8 == 0, "ew_colstats_f16: need M %% 64 == 0, C %% 8 == 0 (M=%d C=%d)", M, C);
-    const int VPP = C / 8;
-    EW_REQUIRE(VPP <= 1024, "ew_colstats_f16: C too large");
-    int PL = VPP >= 256 ? 1 : 256 / VPP;
-    if (PL > 16) PL = 16;                                   // 64 rows: at least 4 per row-lane
-    const size_t lds = (size_t)PL * 2 * C * sizeof(float);
-    EW_REQUIRE(lds <= 64 * 1024, "ew_colstats_f16: C too large for the LDS combine");
-    hipLaunchKernelGGL(colstats_kernel, dim3(M / 64), dim3(VPP * PL), lds, s, x, x_lo, stats, C, ld, VPP, PL);
-    return ew_check_launch("ew_colstats_f16");
-}
-
-extern "C" ew_status ew_colstats_f16(const void* x, const void* x_lo, float* stats, int M, int C, int ld, void* stream) {
-    return ew_colstats_launch((const f16*)x, (const int8_t*)x_lo, stats, M, C, ld, (hipStream_t)stream);
-}
-
-extern "C" ew_status ew_groupnorm_finalize_colstats(const float* stats1, int C1, const float* stats2, int C2, float* out,
-                                                    int n_slabs, int rows, int groups, void* stream) {
-    EW_REQUIRE(stats1 && out && C1 > 0 && C2 >= 0 && (C2 == 0 || stats2), "ew_groupnorm_finalize_colstats: null pointer");
-    EW_REQUIRE(n_slabs > 0 && rows > 0 && rows % 64 == 0 && groups > 0 && (C1 + C2) % groups == 0,
-               "ew_groupnorm_finalize_colstats: need rows %% 64 == 0 and (C1 + C2) %% groups == 0");
-    hipLaunchKernelGGL(gn_finalize_colstats_kernel, dim3(n_slabs * groups), dim3(256), 0, (hipStream_t)stream, stats1, C1,
-                       stats2 ? stats2 : stats1, C2, out, rows, groups);
-    return ew_check_launch("ew_groupnorm_finalize_colstats");
-}
-
-static ew_status gn_apply_launch(const void* x, const void* x_lo, const float* stats, const void* gamma,
-                                 const void* beta, void* y, int n_slabs, int rows, int C_src, int c_off, int C_tot,
-                                 int groups, float eps, int silu, void* stream) {
-    EW_REQUIRE(x && stats && gamma && beta && y, "ew_groupnorm_apply_f16: null pointer");
+    EW_REQUIRE(x && ws && gamma && beta && y, "ew_groupnorm_apply_f16: null pointer");
     EW_REQUIRE(n_slabs > 0 && rows > 0 && C_src > 0 && C_src % 8 == 0 && c_off % 8 == 0 && C_tot % 8 == 0,
                "ew_groupnorm_apply_f16: bad shape");
     EW_REQUIRE(groups > 0 && C_tot % groups == 0 && c_off >= 0 && c_off + C_src <= C_tot, "ew_groupnorm_apply_f16: bad groups");
@@ -587,7 +419,7 @@ static ew_status gn_apply_launch(const void* x, const void* x_lo, const float* s
     EW_REQUIRE(VPP <= 1024, "ew_groupnorm_apply_f16: C_src too large");
     const int PL = VPP >= 256 ? 1 : 256 / VPP;
     const int rpb = 32 * PL;                                   // 32 vectors in flight per thread-column
-    struct { const float* stats; } w{stats};
+    const GnWs w = gn_ws((float*)ws, n_slabs, rows, C_tot);
     dim3 grid(ew_cdiv(rows, rpb), n_slabs);
     if (x_lo)
         hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(VPP * PL), 0, (hipStream_t)stream, (const f16*)x, (const int8_t*)x_lo,

@@ -318,8 +318,10 @@ __global__ __launch_bounds__(256) void resolve_kernel(const u64* __restrict__ zb
 // for all V views.  CF: channels of `faces` (3 | 4); the panorama is always packed RGB.
 template <int CF>
 __global__ __launch_bounds__(256) void cube2equi_kernel(const uint8_t* __restrict__ faces, const int16_t* __restrict__ lut,
-                                                        uint8_t* __restrict__ pano, int V, int HW, int res) {
-    const int nq = HW / 4;
+                                                        uint8_t* __restrict__ pano, int V, int HW, int res, int vec) {
+    // vec: the 4-pixel path stores dwords at pano + (v*HW + 4i)*3, which is 4-byte aligned for every view only when
+    // HW % 4 == 0 (and the base pointers are aligned); otherwise every pixel takes the byte path below
+    const int nq = vec ? HW / 4 : 0;
     const size_t view_sz = (size_t)6 * res * res;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
         const u32x2* L = (const u32x2*)(lut + (size_t)i * 12);       // 12 int16 = 24 bytes, 8-byte aligned
@@ -353,8 +355,8 @@ __global__ __launch_bounds__(256) void cube2equi_kernel(const uint8_t* __restric
             d[2] = (col[2] >> 16) | (col[3] << 8);
         }
     }
-    if (blockIdx.x == 0) {                                            // HW % 4 tail
-        for (int p = nq * 4 + threadIdx.x; p < HW; p += 256) {
+    {                                                                 // byte path: nothing when vec (HW % 4 == 0), every pixel otherwise
+        for (int p = nq * 4 + blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
             const int f = lut[p * 3 + 0], vv = lut[p * 3 + 1], uu = lut[p * 3 + 2];
             const size_t s = ((size_t)f * res + vv) * res + uu;
             for (int v = 0; v < V; ++v)
@@ -606,12 +608,13 @@ extern "C" ew_status ew_cube2equi_gather(const uint8_t* faces, int face_channels
                                          int H, int W, int res, void* stream) {
     EW_REQUIRE(faces && lut && pano && V > 0 && H > 0 && W > 0 && res > 0, "ew_cube2equi_gather: bad args");
     EW_REQUIRE(face_channels == 3 || face_channels == 4, "ew_cube2equi_gather: face_channels must be 3 or 4");
-    EW_REQUIRE(((uintptr_t)lut & 7) == 0 && ((uintptr_t)pano & 3) == 0, "ew_cube2equi_gather: lut / pano alignment");
+    EW_REQUIRE(((uintptr_t)lut & 1) == 0, "ew_cube2equi_gather: lut must be 2-byte aligned");      // unaligned operands take the byte path
     EW_REQUIRE((long long)6 * res * res < (1LL << 31), "ew_cube2equi_gather: face too large");
     const int grid = grid_for((long long)H * W / 4 + 1, 256);
     hipStream_t s = (hipStream_t)stream;
-    if (face_channels == 4) hipLaunchKernelGGL(cube2equi_kernel<4>, dim3(grid), dim3(256), 0, s, faces, lut, pano, V, H * W, res);
-    else hipLaunchKernelGGL(cube2equi_kernel<3>, dim3(grid), dim3(256), 0, s, faces, lut, pano, V, H * W, res);
+    const int vec = ((H * W) % 4 == 0 && (((uintptr_t)pano | (uintptr_t)faces) & 3) == 0 && ((uintptr_t)lut & 7) == 0) ? 1 : 0;
+    if (face_channels == 4) hipLaunchKernelGGL(cube2equi_kernel<4>, dim3(grid), dim3(256), 0, s, faces, lut, pano, V, H * W, res, vec);
+    else hipLaunchKernelGGL(cube2equi_kernel<3>, dim3(grid), dim3(256), 0, s, faces, lut, pano, V, H * W, res, vec);
     return ew_check_launch("ew_cube2equi_gather");
 }
 

@@ -21,6 +21,14 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _aligned(t, n=16):
+    """A contiguous tensor whose data pointer is n-byte aligned: `t` itself when it already is (the usual case: whole
+    allocations), otherwise a fresh copy -- a frame-filtered slice such as conf[frames] or xyz[1:] of a tensor with
+    H*W % 4 != 0 starts at an odd offset, and the 16-byte vector kernels need an aligned base."""
+    t = t.contiguous()
+    return t if t.data_ptr() % n == 0 else t.clone(memory_format=torch.contiguous_format)
+
+
 def _req(t, dtype, name):
     if t.device.type != "cuda":
         raise _lib.EvoWorldHipError(f"{name} must live on the GPU (got {t.device}); evoworld_amd has no CPU path")
@@ -44,12 +52,10 @@ class Res:
     ew_gemm_args), or lo = None when the stream is kept in plain fp16.  The reference runs the stream in fp32
     (unified_loop_consistency.py:188); consumers that need an fp16 MFMA operand read `hi` alone, the residual epilogues and
     the norms read both."""
-    __slots__ = ("hi", "lo", "stats")
+    __slots__ = ("hi", "lo")
 
-    def __init__(self, hi, lo=None, stats=None):
-        # stats: optional fp32 [rows/64, C, 2] column statistics (mean, M2 per 64-row block) emitted by the producing GEMM's
-        # epilogue (ew_gemm_args.colstats) -- what a GroupNorm over this tensor needs instead of a statistics pass
-        self.hi, self.lo, self.stats = hi, lo, stats
+    def __init__(self, hi, lo=None):
+        self.hi, self.lo = hi, lo
 
     @classmethod
     def empty(cls, rows, C, device, split):
@@ -81,7 +87,7 @@ def _hl(x):
 
 def gemm(a, w, out, *, M, N, c1, lda, a2=None, c2=0, lda2=0, bias=None, rowbias=None, rows_per_group=1, ld_rowbias=None,
          r1=None, ld_r1=0, r2=None, ld_r2=0, ld_out=None, mode=A_DENSE, conv=None, tconv=None, act=ACT_NONE,
-         c_acc=1.0, c_r1=1.0, c_r2=1.0, conv_shift=0, colstats=None):
+         c_acc=1.0, c_r1=1.0, c_r2=1.0, conv_shift=0):
     """out = c_acc*act(A@W^T + bias + rowbias) + c_r1*r1 + c_r2*r2  (see ew_gemm_f16).
     conv = (n_img, h_in, w_in, h_out, w_out, stride, upsample); tconv = (B, T, P); conv_shift=1: padding (0,1) taps.
     r1 / r2 / out may be `Res` (split-fp16 residual stream): the lo halves ride along (ew_gemm_args.r1_lo ...)."""
@@ -105,9 +111,29 @@ def gemm(a, w, out, *, M, N, c1, lda, a2=None, c2=0, lda2=0, bias=None, rowbias=
     g.rows_per_group, g.act = rows_per_group, act
     g.c_acc, g.c_r1, g.c_r2 = c_acc, c_r1, c_r2
     g.conv_shift = conv_shift
-    g.colstats = _ptr(colstats)      # fp32 [M/64, N, 2]: column statistics of the result for the consuming GroupNorm
     _lib.check(lib.ew_gemm_f16(ctypes.byref(g), _stream()), "ew_gemm_f16")
     return out
+
+
+_sk_ready = set()
+
+
+def streamk_init():
+    """Allocate generation 3's stream-K workspace for (current device, current stream) once, outside any kernel launch path
+    (ew_gemm_streamk_init; needed before capturing launches into a hipGraph)."""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    if key not in _sk_ready:
+        _lib.check(_lib.load().ew_gemm_streamk_init(_stream()), "ew_gemm_streamk_init")
+        _sk_ready.add(key)
+
+
+def streamk_check():
+    """Raise if a stream-K finisher ever gave up waiting for its partner's partial (the tile it wrote is wrong).  Synchronises:
+    call it where results are handed to the caller (end of a denoise loop / U-Net call / bench), not per launch."""
+    st = _lib.load().ew_gemm_streamk_status()
+    if st != 0:
+        raise _lib.EvoWorldHipError("stream-K hand-over timed out in ew_gemm_f16 (generation 3): results of that launch are invalid"
+                                    if st > 0 else "ew_gemm_streamk_status: HIP error while reading the status word")
 
 
 def linear(x, w, bias=None, out=None, split_out=False, **kw):
@@ -145,47 +171,13 @@ class WorkspacePool:
 SumsPool = WorkspacePool   # former name
 
 
-def colstats_alloc(M, C, device):
-    """fp32 [M/64, C, 2] buffer for ew_gemm_args.colstats / ew_colstats_f16 (every entry is written: no zeroing)."""
-    return torch.empty(M // 64, C, 2, dtype=torch.float32, device=device)
-
-
-def colstats(x):
-    """Stand-alone 64-row-block column statistics of a stored tensor (fp16 [M, C] or `Res`), M % 64 == 0."""
-    lib = _lib.load()
-    h, l = _hl(x)
-    M, C = h.shape
-    st = colstats_alloc(M, C, h.device)
-    _lib.check(lib.ew_colstats_f16(_ptr(h), _ptr(l), _ptr(st), M, C, C, _stream()), "ew_colstats_f16")
-    return st
-
-
 def groupnorm(xs, gamma, beta, n_slabs, rows, eps, silu, groups=32, out=None, pool=None, stats_hi_only=False):
     """GroupNorm(+SiLU) over the channel concat of `xs` (list of [n_slabs*rows, C_i] fp16 tensors or `Res`) ->
-    [n_slabs*rows, sum C_i] fp16.  Deterministic, cancellation-safe statistics.  When a source carries the column statistics
-    its producer emitted (`Res.stats`) and a slab is a whole number of 64-row blocks, there is no statistics pass over the
-    tensors: one finalize over the block statistics (a source without them gets the stand-alone kernel), then apply."""
+    [n_slabs*rows, sum C_i] fp16.  Deterministic shifted statistics: stats per source, one finalize, apply per source."""
     lib = _lib.load()
     srcs = [_hl(x) for x in xs]
     C_tot = sum(h.shape[-1] for h, _ in srcs)
     dev = srcs[0][0].device
-    have = [getattr(x, "stats", None) for x in xs]
-    if rows % 64 == 0 and len(xs) <= 2 and any(s is not None for s in have):
-        sts = [s if s is not None else colstats(x) for s, x in zip(have, xs)]
-        table = pool.take(n_slabs * groups * 2) if pool is not None else torch.empty(n_slabs * groups * 2, dtype=torch.float32, device=dev)
-        c1 = srcs[0][0].shape[-1]
-        c2 = srcs[1][0].shape[-1] if len(srcs) > 1 else 0
-        _lib.check(lib.ew_groupnorm_finalize_colstats(_ptr(sts[0]), c1, _ptr(sts[1]) if len(sts) > 1 else None, c2, _ptr(table),
-                                                      n_slabs, rows, groups, _stream()), "ew_groupnorm_finalize_colstats")
-        if out is None:
-            out = torch.empty(n_slabs * rows, C_tot, dtype=torch.float16, device=dev)
-        off = 0
-        for h, l in srcs:
-            _lib.check(lib.ew_groupnorm_apply_stats_f16(_ptr(h), _ptr(l), _ptr(table), _ptr(gamma), _ptr(beta), _ptr(out), n_slabs,
-                                                        rows, h.shape[-1], off, C_tot, groups, eps, 1 if silu else 0, _stream()),
-                       "ew_groupnorm_apply_stats_f16")
-            off += h.shape[-1]
-        return out
     nws = lib.ew_groupnorm_workspace_floats(n_slabs, rows, C_tot, groups)
     ws = pool.take(nws) if pool is not None else torch.empty(nws, dtype=torch.float32, device=dev)
     if out is None:
@@ -304,6 +296,7 @@ def cube2equi_gather(faces, lut, H, W):
 def select_kth(x, k):
     """x fp32 [n] on the device -> fp32 [2] device tensor (x_(k), x_(k+1)) (0-based, ascending): radix select, no sort."""
     lib = _lib.load()
+    x = _aligned(x)
     _req(x, torch.float32, "x")
     ws = torch.empty(lib.ew_select_workspace_bytes() // 4 + 4, dtype=torch.int32, device=x.device)
     out = torch.empty(2, dtype=torch.float32, device=x.device)
@@ -315,6 +308,7 @@ def filter_compact(conf, thr, xyz, img, img_nchw_hw=0):
     """conf fp32 [n], xyz fp32 [n,3], img fp32 [n,3] (or [S,3,hw] planes with img_nchw_hw = hw) ->
     (xyz_kept [m,3] fp32, rgbx [m,4] uint8 whose first 3 bytes are (img*255) truncated), order preserved."""
     lib = _lib.load()
+    conf, xyz, img = _aligned(conf), _aligned(xyz), _aligned(img)
     _req(conf, torch.float32, "conf"); _req(xyz, torch.float32, "xyz"); _req(img, torch.float32, "img")
     n = conf.numel()
     dev = conf.device
@@ -343,6 +337,7 @@ def splat_cubemap(xyz, rgb, w2c, res, fx, fy, cx, cy, z_near, face_channels=3):
     """xyz [N,3] f32, rgb u8 [N,3] (packed) or [N,4] (RGBX words, possibly a [:, :3] view of one), w2c [V,6,3,4] f32 ->
     faces u8 [V,6,res,res,face_channels], zbuf u64-as-int64 [V,6,res,res]."""
     lib = _lib.load()
+    xyz = _aligned(xyz)
     _req(xyz, torch.float32, "xyz"); _req(w2c, torch.float32, "w2c")
     if rgb.dtype != torch.uint8 or rgb.device.type != "cuda":
         raise TypeError("rgb must be a uint8 device tensor")

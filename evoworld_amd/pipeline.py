@@ -194,6 +194,7 @@ class StableVideoDiffusionPipeline:
             ops.euler_cfg_step(eps, eps.shape[-1], lat, guidance, float(sig[i]), float(sig[i + 1]), x_in, CPAD_IN, T, h, w)
             if callback is not None:
                 callback(i, ts[i], lat)
+        ops.streamk_check()      # synchronises; raises if any stream-K hand-over of the loop timed out (wrong tile)
         return lat[None]
 
     @torch.no_grad()

@@ -225,8 +225,6 @@ class UNetSpatioTemporalConditionModel:
         # BASELINE.json configs[4]: q / k / v projections on the fp8 (e4m3) MFMA path (per-token activation scales,
         # per-output-channel weight scales); off by default -- it changes the numerics contract (tests/test_gpu_fp8.py)
         self.qkv_fp8 = bool(config.get("qkv_fp8", os.environ.get("EW_QKV_FP8", "0") == "1"))
-        # GroupNorm statistics from the producing GEMM's epilogue (ew_gemm_args.colstats) instead of a pass over the tensor
-        self.fused_gn_stats = os.environ.get("EW_FUSED_GN_STATS", "1") != "0"
         self._pos_cache = {}
         for hd, c in zip(cfg["num_attention_heads"], cfg["block_out_channels"]):
             if c // hd != 64:
@@ -270,14 +268,17 @@ class UNetSpatioTemporalConditionModel:
     def packed_tensors(self):
         """Every device tensor of the packed weight set, in a fixed order (3.04 GB fp16 for the full U-Net)."""
         out = []
-        for k in sorted(self.w, key=str):
-            v = self.w[k]
-            if isinstance(v, dict):
-                out += [v[n] for n in sorted(v) if isinstance(v[n], torch.Tensor)]
-            elif isinstance(v, tuple):
-                out += [t for t in v if isinstance(t, torch.Tensor)]
-            elif isinstance(v, torch.Tensor):
+
+        def walk(v):      # dicts in key order, tuples / lists in position order, at any nesting depth (the fp8 q/k/v packs are
+            if isinstance(v, torch.Tensor):                       # (weights, scales) tuples INSIDE the per-block dicts)
                 out.append(v)
+            elif isinstance(v, dict):
+                for n in sorted(v, key=str):
+                    walk(v[n])
+            elif isinstance(v, (tuple, list)):
+                for t in v:
+                    walk(t)
+        walk(self.w)
         return out
 
     def broadcast_weights(self, src=0):
@@ -430,37 +431,19 @@ class UNetSpatioTemporalConditionModel:
     def _res(self, rows, C, dev, head=False):
         return Res.empty(rows, C, dev, self.split_heads if head else self.split_residual)
 
-    def _with_stats(self, out, P):
-        """Attach a column-statistics buffer to a GEMM output that a GroupNorm will consume (P = rows of one frame): the
-        producing kernel's epilogue fills it (ew_gemm_args.colstats), the GroupNorm then needs no statistics pass.  Frames
-        that are not a whole number of 64-row blocks (level 3: 9 x 16) keep the stand-alone statistics kernels."""
-        if not self.fused_gn_stats or P % 64 != 0:
-            return out, None
-        hi = out.hi if isinstance(out, Res) else out
-        st = ops.colstats_alloc(hi.shape[0], hi.shape[1], hi.device)
-        if isinstance(out, Res):
-            out.stats = st
-        else:
-            out = Res(out, None, st)
-        return out, st
-
-    def _conv3x3(self, x, x2, w, b, N, H, W_, Ho, Wo, stride=1, upsample=0, res_out=False, gn_next=False, **kw):
+    def _conv3x3(self, x, x2, w, b, N, H, W_, Ho, Wo, stride=1, upsample=0, res_out=False, **kw):
         c1 = x.shape[-1]
         c2 = x2.shape[-1] if x2 is not None else 0
         M = N * Ho * Wo
         out = self._res(M, w.shape[0], x.device, head="r1" not in kw) if res_out else torch.empty(M, w.shape[0], dtype=torch.float16, device=x.device)
-        out, st = self._with_stats(out, Ho * Wo) if gn_next else (out, None)
-        ops.gemm(x, w, out, M=M, N=w.shape[0], c1=c1, lda=c1, a2=x2, c2=c2, lda2=c2, bias=b,
-                 mode=A_CONV3X3, conv=(N, H, W_, Ho, Wo, stride, upsample), colstats=st, **kw)
-        return out
+        return ops.gemm(x, w, out, M=M, N=w.shape[0], c1=c1, lda=c1, a2=x2, c2=c2, lda2=c2, bias=b,
+                        mode=A_CONV3X3, conv=(N, H, W_, Ho, Wo, stride, upsample), **kw)
 
-    def _convt(self, x, w, b, B, T, P, res_out=False, gn_next=False, **kw):
+    def _convt(self, x, w, b, B, T, P, res_out=False, **kw):
         C = x.shape[-1]
         M = B * T * P
         out = self._res(M, w.shape[0], x.device) if res_out else torch.empty(M, w.shape[0], dtype=torch.float16, device=x.device)
-        out, st = self._with_stats(out, P) if gn_next else (out, None)
-        ops.gemm(x, w, out, M=M, N=w.shape[0], c1=C, lda=C, bias=b, mode=A_CONVT3, tconv=(B, T, P), colstats=st, **kw)
-        return out
+        return ops.gemm(x, w, out, M=M, N=w.shape[0], c1=C, lda=C, bias=b, mode=A_CONVT3, tconv=(B, T, P), **kw)
 
     def _resblock(self, r, xs, tembs, B, T, H, W_):
         """SpatioTemporalResBlock = ResnetBlock2D -> TemporalResnetBlock -> AlphaBlender.
@@ -476,7 +459,7 @@ class UNetSpatioTemporalConditionModel:
         tb_t = tembs[:, self._temb_off[t]:]
         hN = ops.groupnorm(xs, d["n1g"], d["n1b"], N, HW, r.eps, True, pool=self._gn_pool)
         h1 = self._conv3x3(hN, None, d["c1w"], d["c1b"], N, H, W_, H, W_, rowbias=tb_s, rows_per_group=T * HW,
-                           ld_rowbias=self._temb_total, gn_next=True)
+                           ld_rowbias=self._temb_total)
         h2 = ops.groupnorm([h1], d["n2g"], d["n2b"], N, HW, r.eps, True, pool=self._gn_pool)
         if "scw" in d:
             sc = self._res(rows, r.cout, dev, head=True)
@@ -486,15 +469,15 @@ class UNetSpatioTemporalConditionModel:
                      lda2=c2, bias=d["scb"])
         else:
             sc = x1
-        xsp = self._conv3x3(h2, None, d["c2w"], d["c2b"], N, H, W_, H, W_, r1=sc, ld_r1=r.cout, res_out=True, gn_next=True)
+        xsp = self._conv3x3(h2, None, d["c2w"], d["c2b"], N, H, W_, H, W_, r1=sc, ld_r1=r.cout, res_out=True)
         g1 = ops.groupnorm([xsp], d["tn1g"], d["tn1b"], B, T * HW, r.eps, True, pool=self._gn_pool)
         t1 = self._convt(g1, d["t1w"], d["t1b"], B, T, HW, rowbias=tb_t, rows_per_group=T * HW,
-                         ld_rowbias=self._temb_total, gn_next=True)
+                         ld_rowbias=self._temb_total)
         g2 = ops.groupnorm([t1], d["tn2g"], d["tn2b"], B, T * HW, r.eps, True, pool=self._gn_pool)
         # x_temporal = xsp + conv2(..); AlphaBlender (switch_spatial_to_temporal_mix=False, the SpatioTemporalResBlock
         # default the U-Net blocks use): out = a*xsp + (1-a)*x_temporal = xsp + (1-a)*conv2(..), a = sigmoid(mix)
         return self._convt(g2, d["t2w"], d["t2b"], B, T, HW, r1=xsp, ld_r1=r.cout, c_acc=1.0 - d["mix"], c_r1=1.0,
-                           res_out=True, gn_next=True)
+                           res_out=True)
 
     def _pos_emb(self, t, B, T):
         key = (t.p, B, T)
@@ -560,14 +543,14 @@ class UNetSpatioTemporalConditionModel:
         a = d["mix"]  # AlphaBlender: a*x_spatial + (1-a)*x_temporal, x_temporal = hm + ff(..); hb is only a GEMM operand
         hb = ops.linear(ffh, d["t_f2w"], d["t_f2b"], c_acc=1.0 - a, r1=hm, ld_r1=C, c_r1=1.0 - a, r2=h, ld_r2=C, c_r2=a)
         del ffh
-        out, st = self._with_stats(self._res(rows, C, dev), S)        # feeds the next resblock's norm1 (or a skip concat)
-        return ops.linear(hb, d["pow"], d["pob"], out=out, r1=x, ld_r1=C, colstats=st)
+        return ops.linear(hb, d["pow"], d["pob"], out=self._res(rows, C, dev), r1=x, ld_r1=C)
 
     # ---------------- forward ----------------
     def forward_nhwc(self, x, timestep, encoder_hidden_states, added_time_ids, B, T, H, W_, taps=None):
         """x: fp16 [B*T*H*W, 64] channels-last (18 real channels, zero padded) -> fp16 [B*T*H*W, 4]."""
         cfg, Wt = self._cfg, self.w
         dev = x.device
+        ops.streamk_init()      # stream-K workspace of this (device, stream): allocated here, never inside a launch / graph capture
         if getattr(self, "_gn_pool", None) is None or self._gn_pool.buf.device != dev:
             self._gn_pool = ops.WorkspacePool(dev)
         self._gn_pool.reset()
@@ -586,7 +569,7 @@ class UNetSpatioTemporalConditionModel:
         ehs = encoder_hidden_states.to(device=dev, dtype=torch.float16).reshape(B, -1).contiguous()
         cvecs = ops.linear(ehs, Wt["cv_w"], Wt["cv_b"])               # all 32 cross-attention vectors at once
 
-        h = self._conv3x3(x, None, *Wt["conv_in"], N, H, W_, H, W_, res_out=True, gn_next=True)
+        h = self._conv3x3(x, None, *Wt["conv_in"], N, H, W_, H, W_, res_out=True)
         if taps is not None:
             taps["conv_in"] = (h.float(), H, W_)
         skips = [(h, H, W_)]
@@ -598,7 +581,7 @@ class UNetSpatioTemporalConditionModel:
                 skips.append((h, H, W_))
             if blk.down:
                 w, b = Wt[blk.down.p]
-                h = self._conv3x3(h.hi, None, w, b, N, H, W_, H // 2, W_ // 2, stride=2, res_out=True, gn_next=True)
+                h = self._conv3x3(h.hi, None, w, b, N, H, W_, H // 2, W_ // 2, stride=2, res_out=True)
                 H, W_ = H // 2, W_ // 2
                 skips.append((h, H, W_))
             if taps is not None:
@@ -618,7 +601,7 @@ class UNetSpatioTemporalConditionModel:
                     h = self._transformer(blk.attn[l], h, cvecs, B, T, H, W_)
             if blk.up:
                 w, b = Wt[blk.up.p]
-                h = self._conv3x3(h.hi, None, w, b, N, H, W_, 2 * H, 2 * W_, upsample=1, res_out=True, gn_next=True)
+                h = self._conv3x3(h.hi, None, w, b, N, H, W_, 2 * H, 2 * W_, upsample=1, res_out=True)
                 H, W_ = 2 * H, 2 * W_
             if taps is not None:
                 taps[f"up{bi}"] = (h.float(), H, W_)
@@ -640,6 +623,7 @@ class UNetSpatioTemporalConditionModel:
         eps = self.forward_nhwc(x, timestep, encoder_hidden_states, added_time_ids, B, T, H, W_, taps=taps)
         oc = self._cfg["out_channels"]
         out = ops.nhwc_f16_to_nchw_f32(eps, B * T, oc, H, W_, oc).reshape(B, T, oc, H, W_)
+        ops.streamk_check()     # a stream-K hand-over that timed out leaves a wrong tile: never return that silently
         if not return_dict:
             return (out,)
         return SimpleNamespace(sample=out)

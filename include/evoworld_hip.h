@@ -89,12 +89,6 @@ typedef struct ew_gemm_args {
     /* EW_A_CONV3X3 tap origin: 0 = iy = oy*stride + ky - 1 (symmetric padding 1); 1 = iy = oy*stride + ky, zero beyond the
      * bottom / right edge (F.pad(x, (0,1,0,1)) + stride-2 conv of diffusers Downsample2D(padding=0), the VAE encoder). */
     int conv_shift;
-    /* ABI 5.  Optional float [M/64][N][2]: (mean, M2) of every output column over each block of 64 consecutive output rows --
-     * the statistics a GroupNorm over this tensor needs (ew_groupnorm_finalize_colstats).  Generation-3 kernels emit them from
-     * the epilogue (no extra pass over the tensor); otherwise ew_gemm_f16 runs ew_colstats_f16 on the stored result.  Needs
-     * M % 64 == 0; not available with GEGLU.  Replaces the reference's torch.nn.GroupNorm statistics pass
-     * (diffusers ResnetBlock2D / TemporalResnetBlock norm1/norm2, evoworld/trainer/unet_plucker.py:161-233). */
-    void* colstats;
 } ew_gemm_args;
 
 ew_status ew_gemm_f16(const ew_gemm_args* args, void* stream);
@@ -107,8 +101,7 @@ int ew_get_gemm_generation(void);
 /* Debug aid for measurement tools (bench.py): rocprof-style name of the kernel variant the last ew_gemm_f16 call on this
    thread's library instance launched, e.g. "gemm3_kernel<0, 8>".  Not part of the reference surface. */
 const char* ew_gemm_last_kernel(void);
-void ew_set_gemm_debug(int flags);   /* measurement-only switches (bit0: skip stores, bit1: skip epilogue, bit2: no stream-K tail,
-                                        bit4: column statistics by the stand-alone kernel instead of the epilogue); 0 = normal */
+void ew_set_gemm_debug(int flags);   /* measurement-only switches (bit0: skip stores, bit1: skip epilogue, bit2: no stream-K tail); 0 = normal */
 /* Generation 3 splits the last round of output tiles along K over its 256 persistent workgroups when whole-tile rounds would
  * leave > 4 % of the chip idle (stream-K tail: fp32 partial accumulators handed over through a library-owned uncached
  * workspace, one per (device, stream), allocated on first use: 84 MB + 67 MB for the 256-wide instance).  Deterministic: the
@@ -143,20 +136,6 @@ ew_status ew_groupnorm_finalize(float* ws, int n_slabs, int rows, int C_tot, int
 ew_status ew_groupnorm_apply_f16(const void* x, const void* x_lo, const float* ws, const void* gamma, const void* beta,
                                  void* y, int n_slabs, int rows, int C_src, int c_off, int C_tot, int groups, float eps,
                                  int silu, void* stream);
-
-/* Round 3: GroupNorm from 64-row-block column statistics (ew_gemm_args.colstats).
- * ew_colstats_f16: stats[M/64][C][2] = (mean, M2) per channel and 64-row block of a stored tensor x [M, C] (row stride ld
- *   elements; x_lo = optional lo8 companion) -- the stand-alone form of what the generation-3 epilogues emit.
- * ew_groupnorm_finalize_colstats: merges blocks and channels into out[n_slabs][groups][2] = (mean, biased variance); the
- *   normalised tensor is the channel concat of up to two sources (stats1: C1 channels, stats2: C2 channels or NULL / 0);
- *   rows (per slab) % 64 == 0.  Deterministic (fixed reduction order), cancellation-safe.
- * ew_groupnorm_apply_stats_f16: ew_groupnorm_apply_f16 with the (mean, variance) table given directly. */
-ew_status ew_colstats_f16(const void* x, const void* x_lo, float* stats, int M, int C, int ld, void* stream);
-ew_status ew_groupnorm_finalize_colstats(const float* stats1, int C1, const float* stats2, int C2, float* out, int n_slabs,
-                                         int rows, int groups, void* stream);
-ew_status ew_groupnorm_apply_stats_f16(const void* x, const void* x_lo, const float* stats, const void* gamma, const void* beta,
-                                       void* y, int n_slabs, int rows, int C_src, int c_off, int C_tot, int groups, float eps,
-                                       int silu, void* stream);
 
 /* LayerNorm over the last dim (fp16 in/out, fp32 two-pass statistics).  x_lo (may be NULL): lo8 companion of a split
  * residual stream (int8).  Optional fused pre-add: x' = x + addvec[row / rows_per_group][:] is what gets normalised, and x' is

@@ -47,6 +47,7 @@ class TimestepEmbedding(nn.Module):
         return self.linear_2(F.silu(self.linear_1(x)))
 
 
+ATTN_Q = None  # analysis knob (tests/analysis_fp16_floor.py): rounding applied to the attention core's matmul operands q, k, v, P
 RES_Q = None   # analysis knob (tests/analysis_fp16_floor.py): a function applied at every residual-stream tensor
 
 
@@ -154,7 +155,12 @@ class Attention(nn.Module):
         q = q.view(B, S, h, -1).transpose(1, 2)
         k = k.view(B, k.shape[1], h, -1).transpose(1, 2)
         v = v.view(B, v.shape[1], h, -1).transpose(1, 2)
-        o = F.scaled_dot_product_attention(q, k, v)
+        if ATTN_Q is None:
+            o = F.scaled_dot_product_attention(q, k, v)
+        else:       # analysis: the four MFMA operands of the attention core (q, k, P, v) rounded by ATTN_Q, everything else fp32
+            q, k, v = ATTN_Q(q), ATTN_Q(k), ATTN_Q(v)
+            p_ = torch.softmax(q @ k.transpose(-1, -2) * (q.shape[-1] ** -0.5), dim=-1)
+            o = ATTN_Q(p_) @ v
         o = o.transpose(1, 2).reshape(B, S, -1)
         return self.to_out[0](o)
 

@@ -113,3 +113,59 @@ def per_tensor_ablation():
 
 if __name__ == "__main__" and "--per-tensor" in sys.argv:
     per_tensor_ablation()
+
+
+def per_timestep_floor(steps_list=(2, 3, 25)):
+    """Round 3: the fp16-operand floor of WHOLE short clips.  For the inputs of tests/test_gpu_pipeline.py
+    (tiny config, T=4, 16x32 latents, seed 5) the oracle denoise loop runs twice per step count: fp32 everywhere, and with the
+    operands of every conv / linear (weights too) rounded to fp16 and everything else fp32 -- the floor of any design that feeds
+    fp16 operands to the MFMA, before any storage or attention-internal rounding.  Prints, per step, the rel-L2 of the model
+    output (eps) and of the latents, so the 2- / 3-step clip tolerances can be read against what fp16 operands alone cost at
+    those noise levels."""
+    from evoworld_amd.scheduler import EulerDiscreteScheduler
+    from oracle.reproject_ref import euler_cfg_step_ref
+    cfg = tiny_config()
+    sd = {k: v.half().float() for k, v in random_state_dict({**DEFAULT_CONFIG, **cfg}, 0).items()}
+    model = UNetRef(**cfg).eval()
+    model.load_state_dict(sd)
+    mm = (torch.nn.Conv2d, torch.nn.Conv3d, torch.nn.Linear)
+    T, h, w = 4, 16, 32
+    g = torch.Generator().manual_seed(5)
+    lat0, il = torch.randn(1, T, 4, h, w, generator=g), torch.randn(1, T + 1, 4, h, w, generator=g)
+    ehs, pl = torch.randn(1, 1, cfg["cross_attention_dim"], generator=g), torch.randn(1, T, 6, h, w, generator=g)
+    il2 = torch.cat([torch.zeros_like(il), il])
+    cond = torch.cat([il2[:, 0:1].repeat(1, T, 1, 1, 1), il2[:, 1:], torch.cat([pl, pl])], dim=2)
+    e2 = torch.cat([torch.zeros_like(ehs), ehs])
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
+    guid = torch.linspace(1.0, 3.0, T)
+    import oracle.unet_ref as O
+    for attn_ops in (False, True):
+        # attn_ops: ALSO the four matmul operands of the attention core (q, k, P, v) are fp16 -- every MFMA operand of the
+        # network then is; nothing else (no storage rounding, fp32 softmax / norms / residual stream)
+        O.ATTN_Q = r16 if attn_ops else None
+        label = "fp16 operands of every conv / linear" + (" AND of the attention matmuls (q, k, P, v)" if attn_ops else "")
+        for steps in steps_list:
+            s = EulerDiscreteScheduler()
+            s.set_timesteps(steps)
+            lat_ref = lat0 * s.init_noise_sigma
+            lat_q = lat_ref.clone()
+            print(f"--- {steps}-step clip, {label} (sigmas {[round(float(v), 4) for v in s.sigmas[:4]]} ...)")
+            for i in range(steps):
+                sig, sign = float(s.sigmas[i]), float(s.sigmas[i + 1])
+                xr = torch.cat([torch.cat([lat_ref, lat_ref]) / (sig ** 2 + 1) ** 0.5, cond], dim=2)
+                xq = torch.cat([torch.cat([lat_q, lat_q]) / (sig ** 2 + 1) ** 0.5, cond], dim=2)
+                O.ATTN_Q = None
+                eps_r = run(model, (xr, s.timesteps[i], e2, ids))
+                O.ATTN_Q = r16 if attn_ops else None
+                eps_same = run(model, (xr, s.timesteps[i], e2, ids), pre=r16, kinds_pre=mm)        # same input: the per-forward floor
+                eps_q = run(model, (xq, s.timesteps[i], e2, ids), pre=r16, kinds_pre=mm)           # own trajectory
+                lat_ref = euler_cfg_step_ref(eps_r[0:1], eps_r[1:2], lat_ref, guid, sig, sign)
+                lat_q = euler_cfg_step_ref(eps_q[0:1], eps_q[1:2], lat_q, guid, sig, sign)
+                if steps <= 3 or i in (0, steps // 2, steps - 2, steps - 1):
+                    print(f"  step {i:2d} sigma {sig:9.4f}: eps floor (same input) {rel(eps_same, eps_r):.2e}   latents after the step {rel(lat_q, lat_ref):.2e}")
+            print(f"  => {steps}-step clip: final latents rel-L2 {rel(lat_q, lat_ref):.2e}")
+    O.ATTN_Q = None
+
+
+if __name__ == "__main__" and "--per-timestep" in sys.argv:
+    per_timestep_floor()

@@ -72,3 +72,30 @@ def test_unet_tiny_fp8_qkv_vs_oracle():
     e = rel_l2(got.cpu(), ref(x, t, ehs, ids))
     print(f"unet tiny forward with fp8 q/k/v rel-L2 {e:.3e}")
     assert torch.isfinite(got).all() and e < 1e-2
+
+
+def test_fp8_weight_packs_travel_with_packed_tensors():
+    """Round-2 advisor: the fp8 q/k/v packs are (weights, scales) tuples nested in the per-block dicts; `packed_tensors()` (what
+    `broadcast_weights` ships and `weights_checksum` sums) must include them, or every rank but 0 keeps all-zero fp8 weights.
+    Simulates the broadcast in one process: copy rank 0's packed tensors into a from_zeros replica, forwards must be identical."""
+    from evoworld_amd.unet import UNetSpatioTemporalConditionModel
+    from oracle.unet_ref import tiny_config
+    cfg = tiny_config()
+    src = UNetSpatioTemporalConditionModel.from_random(seed=3, device=DEV, qkv_fp8=True, **cfg)
+    dst = UNetSpatioTemporalConditionModel.from_zeros(device=DEV, qkv_fp8=True, **cfg)
+    a, b = src.packed_tensors(), dst.packed_tensors()
+    assert len(a) == len(b) and any(t.dtype == torch.uint8 for t in a)          # the e4m3 bytes are in the list
+    for s_, d_ in zip(a, b):
+        assert s_.shape == d_.shape and s_.dtype == d_.dtype
+        d_.copy_(s_)
+    for k in src.w:
+        if isinstance(src.w[k], dict) and "mix" in src.w[k]:
+            dst.w[k]["mix"] = src.w[k]["mix"]
+    assert abs(src.weights_checksum() - dst.weights_checksum()) == 0.0
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, cfg["num_frames"], 18, 16, 32, generator=g).to(DEV)
+    ehs = torch.randn(2, 1, cfg["cross_attention_dim"], generator=g).to(DEV)
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * 2).to(DEV)
+    ya = src(x, torch.tensor(1.0), ehs, ids, return_dict=False)[0]
+    yb = dst(x, torch.tensor(1.0), ehs, ids, return_dict=False)[0]
+    assert torch.equal(ya, yb) and float(ya.abs().mean()) > 0

@@ -177,3 +177,40 @@ def test_filter_compact_matches_boolean_mask(nchw):
     assert v.shape[0] == int(keep.sum())
     assert np.array_equal(v.cpu().numpy(), xyz.numpy()[keep])
     assert np.array_equal(rgbx[:, :3].cpu().numpy(), cols[keep])
+
+
+@pytest.mark.parametrize("H,W,ch", [(5, 9, 3), (5, 9, 4), (6, 10, 3)])
+def test_cube2equi_gather_any_pixel_count(H, W, ch):
+    """H*W % 4 != 0: the dword-store path would be misaligned for views >= 1 -- every pixel takes the byte path (round-2 advisor)."""
+    from evoworld_amd import ops
+    g = torch.Generator().manual_seed(3)
+    V, res = 3, 8
+    faces = torch.randint(0, 256, (V, 6, res, res, ch), dtype=torch.uint8, generator=g)
+    lut = torch.stack([torch.randint(0, 6, (H, W), generator=g), torch.randint(0, res, (H, W), generator=g),
+                       torch.randint(0, res, (H, W), generator=g)], -1).to(torch.int16)
+    got = ops.cube2equi_gather(faces.to(DEV), lut.to(DEV), H, W).cpu()
+    f, vv, uu = lut[..., 0].long(), lut[..., 1].long(), lut[..., 2].long()
+    want = faces[:, f, vv, uu][..., :3]
+    assert torch.equal(got, want)
+
+
+def test_select_and_splat_accept_unaligned_views():
+    """conf[frames] / xyz[1:] style views of tensors whose H*W is not a multiple of 4 start at odd offsets: the wrappers copy
+    them to an aligned buffer instead of failing the 16-byte alignment check (round-2 advisor)."""
+    from evoworld_amd import ops
+    g = torch.Generator().manual_seed(4)
+    base = torch.rand(3 * 37 + 5, generator=g).to(DEV)
+    view = base[37 + 1:]                                            # data_ptr offset 152 bytes: 8-byte aligned only
+    assert view.data_ptr() % 16 != 0
+    k = 20
+    got = ops.select_kth(view, k).cpu()
+    srt = torch.sort(view.cpu()).values
+    assert torch.equal(got, srt[k:k + 2])
+    xyz_all = (torch.rand(50, 3, generator=g) * 4 - 2).to(DEV)
+    xyz = xyz_all[1:]
+    assert xyz.data_ptr() % 16 != 0
+    rgb = torch.randint(0, 256, (49, 3), dtype=torch.uint8, generator=g).to(DEV)
+    w2c = torch.eye(4)[:3][None, None].repeat(1, 6, 1, 1).contiguous().to(DEV)
+    f1, z1 = ops.splat_cubemap(xyz, rgb, w2c, 16, 8.0, 8.0, 8.0, 8.0, 0.1)
+    f2, z2 = ops.splat_cubemap(xyz.clone(), rgb, w2c, 16, 8.0, 8.0, 8.0, 8.0, 0.1)
+    assert torch.equal(f1, f2) and torch.equal(z1, z2)
