@@ -73,10 +73,10 @@ class ResnetBlock2D(nn.Module):
 
     def forward(self, x, temb):
         h = self.conv1(F.silu(self.norm1(x)))
-        h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
+        h = _rq(h + self.time_emb_proj(F.silu(temb))[:, :, None, None], "res_h1")    # analysis tag: GroupNorm input between the convs
         h = self.conv2(F.silu(self.norm2(h)))
         if self.conv_shortcut is not None:
-            x = self.conv_shortcut(x)
+            x = _rq(self.conv_shortcut(x), "res_sc")
         return _rq(x + h, "res_sp")
 
 
@@ -92,7 +92,7 @@ class TemporalResnetBlock(nn.Module):
     def forward(self, x, temb):  # x [B,C,T,H,W], temb [B,T,Ct]
         h = self.conv1(F.silu(self.norm1(x)))
         t = self.time_emb_proj(F.silu(temb))[:, :, :, None, None].permute(0, 2, 1, 3, 4)
-        h = h + t
+        h = _rq(h + t, "res_t1")
         h = self.conv2(F.silu(self.norm2(h)))
         return x + h
 

@@ -104,7 +104,7 @@ def per_tensor_ablation():
     ref = run(model, inputs)
     base = rel(run(model, inputs, pre=r16, kinds_pre=mm), ref)
     print(f"operands only: {base:.3e}")
-    for tag in ("res_sp", "res_out", "t_out", "proj_in", "s_attn", "s_ff", "t_ffin", "t_attn", "blend"):
+    for tag in ("res_sp", "res_out", "t_out", "proj_in", "s_attn", "s_ff", "t_ffin", "t_attn", "blend", "res_h1", "res_t1", "res_sc"):
         O.RES_Q = lambda t, tg, tag=tag: r16(t) if tg == tag else t
         e = rel(run(model, inputs, pre=r16, kinds_pre=mm), ref)
         print(f"  + fp16 {tag:8s}: {e:.3e}   added squared rel-L2 {(e * e - base * base) * 1e6:.3f}e-6")

@@ -7,10 +7,14 @@ from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
 
-# Stated tolerances = 1.5 x the values measured on MI355X with the split-fp16 residual stream, so a 2x
-# regression fails: 3-step clips measure 1.24e-3 / 1.40e-3 (mask_mem), the 25-step clip 4.1e-4, the 2-step clip on the
-# smooth stand-in VAE latents 2.2e-3 (two steps = sigma 700 -> 0.002 -> 0: the output is one raw model prediction).
-TOL_CLIP3 = 2.1e-3
+# Stated tolerance (north_star): 1e-3 rel-L2 on the clip the pipeline returns after the full 25-step schedule: measured 4.3e-4,
+# asserted at 6.2e-4.  SHORT clips are a different quantity: two or three Euler steps from sigma = 700 return (almost) ONE raw
+# model prediction amplified by the CFG combination, and for these inputs the fp16-operand floor alone -- operands of every
+# conv / linear and of the attention matmuls rounded to fp16, everything else fp32 -- is 1.04e-3 ... 1.06e-3
+# (tests/analysis_fp16_floor.py --per-timestep): no design on fp16 MFMA operands can meet 1e-3 there.  The build measures
+# 1.25e-3 / 1.36e-3 (mask_mem) = 1.2 ... 1.3 x that floor; asserted at 1.6e-3 (1.5 x the floor).  The 2-step clip through the
+# stand-in VAE (smooth latents, the worst case measured) is 2.3e-3, asserted at 3.4e-3.
+TOL_CLIP3 = 1.6e-3
 TOL_CLIP25 = 6.2e-4
 TOL_CLIP2_STANDIN = 3.4e-3
 
@@ -234,4 +238,4 @@ def test_full_size_clip_vs_oracle():
     e = rel_l2(out.cpu(), final)
     print(f"FULL-SIZE clip ({steps} steps, T=25, 72x128 latents, 1.52 B parameters) final rel-L2 {e:.3e}", flush=True)
     assert torch.isfinite(out).all()
-    assert e < (1e-3 if steps >= 20 else 2.1e-3)
+    assert e < (1e-3 if steps >= 20 else TOL_CLIP3)

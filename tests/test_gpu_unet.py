@@ -1,10 +1,13 @@
 """-m gpu: the HIP U-Net (through the C ABI) against the fp32 CPU oracle on the same seeded weights/inputs.
-Tolerance (stated): fp16 MFMA operands, fp32 accumulation, split-fp16 (hi + lo) residual stream.  Against the fp32 oracle
-on the same fp16-representable checkpoint one U-Net forward measures 8.9e-4 rel-L2 end to end (BASELINE.json: 1e-3) and
-<= 1.24e-3 at every tapped block output; the assertions are 1.5 x the measured values so that a 2x regression fails
-(the plain-fp16 stream, EW_RESIDUAL=fp16, measures 1.33e-3 and fails them)."""
-TOL_FORWARD = 1.3e-3
-TOL_TAP = 1.9e-3
+Stated tolerance (BASELINE.json north_star): 1e-3 rel-L2 on the model OUTPUT.  fp16 MFMA operands, fp32 accumulation, split
+(hi + lo8) residual stream: one forward measures 8.9e-4 (tiny config), 9.2e-4 (T=25) and 8.2e-4 at the full config-2 size
+against the fp32 oracle -- of which 7.5e-4 ... 8.0e-4 is the floor of ANY design that feeds fp16 operands to the MFMA
+(tests/analysis_fp16_floor.py: operands of every conv / linear AND of the attention matmuls rounded, nothing else).
+The OUTPUT assertion is the north_star's 1e-3.  The per-block TAPS are internal tensors, not outputs: the error peaks at the
+bottleneck (mid / up0: 1.26e-3 tiny, 1.13e-3 full size) and falls again towards the output; they are asserted at 1.5e-3
+(a 20 % regression of the worst tap fails)."""
+TOL_FORWARD = 1.0e-3
+TOL_TAP = 1.5e-3
 import pytest
 import torch
 
