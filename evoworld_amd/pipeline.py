@@ -26,6 +26,32 @@ from .scheduler import EulerDiscreteScheduler
 from .unet import CPAD_IN
 
 
+_RANDN_CACHE = {}
+
+
+def _randn_like_reference(shape, generator, device, dtype=torch.float32):
+    """diffusers `randn_tensor(shape, generator, device)`: a CPU generator draws on the host and the tensor is moved.  The
+    reference re-seeds ONE CPU generator identically for every window (`torch.manual_seed(-1)`, navigator_evoworld.py:198), so
+    the 46 M-value augmentation noise and the latents are the same tensors window after window: draws are memoised on
+    (generator state, shape, dtype) -- a hit restores the generator to the state the real draw would have left it in and returns
+    the device-resident tensor (0.35 s of host RNG + 184 MB of PCIe per window at 576x1024x25 otherwise).  Bit-identical to
+    drawing again by construction; the returned tensor must not be modified in place."""
+    if not isinstance(generator, torch.Generator):
+        return torch.randn(shape, generator=generator, device=device, dtype=dtype)
+    if generator.device.type != "cpu":
+        return torch.randn(shape, generator=generator, device=generator.device, dtype=dtype).to(device)
+    key = (bytes(generator.get_state().numpy()), tuple(shape), dtype, str(device))
+    hit = _RANDN_CACHE.get(key)
+    if hit is not None:
+        generator.set_state(hit[1])
+        return hit[0]
+    t = torch.randn(shape, generator=generator, device="cpu", dtype=dtype).to(device)
+    if len(_RANDN_CACHE) >= 4:
+        _RANDN_CACHE.pop(next(iter(_RANDN_CACHE)))
+    _RANDN_CACHE[key] = (t, generator.get_state().clone())
+    return t
+
+
 def _append_dims(x, target_dims):
     """pipeline_evoworld.py:128-133"""
     d = target_dims - x.ndim
@@ -161,8 +187,7 @@ class StableVideoDiffusionPipeline:
             raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective "
                              f"batch size of {batch_size}.")
         if latents is None:
-            gdev = generator.device if isinstance(generator, torch.Generator) else device
-            latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
+            latents = _randn_like_reference(shape, generator, device, dtype)
         else:
             latents = latents.to(device)
         return latents * self.scheduler.init_noise_sigma
@@ -231,16 +256,13 @@ class StableVideoDiffusionPipeline:
             img = img / 2.0 + 0.5                                                           # :579
             image_embeddings = self._encode_image(img[:, 0])
             flat = img.flatten(0, 1) * 2.0 - 1.0                                            # VideoProcessor.preprocess
-            noise = image_noise if image_noise is not None else torch.randn(
-                flat.shape, generator=generator, device=(generator.device if isinstance(generator, torch.Generator) else dev),
-                dtype=flat.dtype)
+            noise = image_noise if image_noise is not None else _randn_like_reference(flat.shape, generator, dev, flat.dtype)
             flat = flat + noise_aug_strength * noise.to(dev)                                 # :599-600
             image_latents = self.vae.encode(flat).latent_dist.mode().reshape(1, -1, 4, height // 8, width // 8)
         elif image_noise is None and isinstance(generator, torch.Generator) and memorized_pixel_values is not None:
             # injected conditioning: keep the reference's RNG order anyway -- the [1+T,3,H,W] augmentation-noise draw comes
             # first (:596-600), so the latents below are the generator's SECOND draw, as in the reference
-            torch.randn((1 + memorized_pixel_values.shape[1],) + tuple(image.shape[1:]), generator=generator,
-                        device=generator.device, dtype=torch.float32)
+            _randn_like_reference((1 + memorized_pixel_values.shape[1],) + tuple(image.shape[1:]), generator, dev)
         image_latents = image_latents.to(device=dev, dtype=torch.float32).clone()
         image_embeddings = image_embeddings.to(device=dev, dtype=torch.float32)
         if image_latents.shape[1] != num_frames + 1:

@@ -102,6 +102,27 @@ def test_scheduler_custom_sigmas_and_stage_duck_types():
     assert st.image_encoder(torch.rand(1, 3, 224, 224)).image_embeds.shape == (1, 64)
 
 
+def test_window_rng_draws_are_memoised_bit_exactly():
+    """The reference re-seeds one CPU generator per window (navigator_evoworld.py:198): the pipeline memoises the draws on the
+    generator state; a hit must return the same values AND leave the generator where a real draw would have."""
+    from evoworld_amd.pipeline import _RANDN_CACHE, _randn_like_reference
+    _RANDN_CACHE.clear()
+    g = torch.manual_seed(-1)
+    a1 = _randn_like_reference((2, 3, 5), g, "cpu")
+    b1 = _randn_like_reference((1, 7), g, "cpu")
+    tail1 = torch.randn(4, generator=g)
+    g = torch.manual_seed(-1)
+    a2 = _randn_like_reference((2, 3, 5), g, "cpu")              # cache hits
+    b2 = _randn_like_reference((1, 7), g, "cpu")
+    tail2 = torch.randn(4, generator=g)
+    ref = torch.manual_seed(-1)
+    want_a, want_b, want_t = torch.randn((2, 3, 5), generator=ref), torch.randn((1, 7), generator=ref), torch.randn(4, generator=ref)
+    assert a2 is a1 and b2 is b1 and len(_RANDN_CACHE) == 2
+    assert torch.equal(a1, want_a) and torch.equal(b1, want_b) and torch.equal(tail1, want_t) and torch.equal(tail2, want_t)
+    g = torch.manual_seed(7)                                    # another seed: no false hit
+    assert not torch.equal(_randn_like_reference((2, 3, 5), g, "cpu"), a1)
+
+
 def test_geometry_and_rays_golden(golden_dir):
     from evoworld_amd.geometry import xyz_euler_to_four_by_four_matrix_batch, xyz_euler_to_three_by_four_matrix_batch
     from evoworld_amd.plucker import equirectangular_to_ray
