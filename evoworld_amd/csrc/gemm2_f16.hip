@@ -596,7 +596,10 @@ ew_status dispatch_epi(const GemmP& p, hipStream_t s) {
             return dispatch_tile<MODE, 16 | 7>(p, s);
         } else {
             if ((mask & 5) == 0) return dispatch_tile<MODE, 16 | 2>(p, s);
-            ew_set_error("ew_gemm_f16: conv modes carry the split residual only with r1 (no row-bias / r2)");
+            // row-bias + split output (round 3: the conv1 / temporal conv1 outputs of the resblocks, GroupNorm inputs whose fp16
+            // rounding was the largest remaining storage term of the parity budget); r1 may be null (zero page)
+            if ((mask & 4) == 0) return dispatch_tile<MODE, 16 | 3>(p, s);
+            ew_set_error("ew_gemm_f16: conv modes carry the split residual with row-bias / r1 only (no r2)");
             return EW_ERR_UNSUPPORTED;
         }
     }

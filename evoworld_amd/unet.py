@@ -225,6 +225,10 @@ class UNetSpatioTemporalConditionModel:
         # BASELINE.json configs[4]: q / k / v projections on the fp8 (e4m3) MFMA path (per-token activation scales,
         # per-output-channel weight scales); off by default -- it changes the numerics contract (tests/test_gpu_fp8.py)
         self.qkv_fp8 = bool(config.get("qkv_fp8", os.environ.get("EW_QKV_FP8", "0") == "1"))
+        # conv1 output of every resblock (the GroupNorm input between the two 3x3 convs) carried split too: in the per-tensor
+        # ablation (tests/analysis_fp16_floor.py --per-tensor, tag res_h1) its fp16 rounding was the largest storage term left
+        # (0.15e-6 of squared rel-L2 against 0.56e-6 for fp16 MFMA operands alone); EW_SPLIT_H1=0 restores the plain fp16 tensor
+        self.split_h1 = self.split_heads and os.environ.get("EW_SPLIT_H1", "1") != "0"
         self._pos_cache = {}
         for hd, c in zip(cfg["num_attention_heads"], cfg["block_out_channels"]):
             if c // hd != 64:
@@ -459,7 +463,7 @@ class UNetSpatioTemporalConditionModel:
         tb_t = tembs[:, self._temb_off[t]:]
         hN = ops.groupnorm(xs, d["n1g"], d["n1b"], N, HW, r.eps, True, pool=self._gn_pool)
         h1 = self._conv3x3(hN, None, d["c1w"], d["c1b"], N, H, W_, H, W_, rowbias=tb_s, rows_per_group=T * HW,
-                           ld_rowbias=self._temb_total)
+                           ld_rowbias=self._temb_total, res_out=self.split_h1)
         h2 = ops.groupnorm([h1], d["n2g"], d["n2b"], N, HW, r.eps, True, pool=self._gn_pool)
         if "scw" in d:
             sc = self._res(rows, r.cout, dev, head=True)
