@@ -16,7 +16,7 @@ ABI_VERSION = 5
 
 # every symbol declared in include/evoworld_hip.h
 SYMBOLS = [
-    "ew_abi_version", "ew_last_error", "ew_gemm_f16", "ew_set_gemm_generation", "ew_get_gemm_generation", "ew_set_gemm_debug", "ew_gemm_last_kernel", "ew_gemm_streamk_status", "ew_gemm_streamk_init", "ew_groupnorm_workspace_floats", "ew_groupnorm_stats_f16", "ew_groupnorm_finalize", "ew_groupnorm_apply_f16",
+    "ew_abi_version", "ew_last_error", "ew_gemm_f16", "ew_set_gemm_generation", "ew_get_gemm_generation", "ew_set_gemm_debug", "ew_gemm_last_kernel", "ew_gemm_streamk_status", "ew_gemm_streamk_init", "ew_ff_geglu320_f16", "ew_groupnorm_workspace_floats", "ew_groupnorm_stats_f16", "ew_groupnorm_finalize", "ew_groupnorm_apply_f16",
     "ew_layernorm_f16", "ew_attn_spatial_f16", "ew_attn_temporal_f16", "ew_nchw_f32_to_nhwc_f16",
     "ew_nhwc_f16_to_nchw_f32", "ew_softmax_rows_f16", "ew_time_conv3_f32", "ew_euler_cfg_step", "ew_plucker_embed", "ew_cube2equi_gather",
     "ew_depth_unproject", "ew_select_workspace_bytes", "ew_select_kth_f32", "ew_filter_compact_workspace_bytes",
@@ -37,6 +37,16 @@ class GemmArgs(ctypes.Structure):
         ("stride", c_int), ("upsample", c_int), ("tB", c_int), ("tT", c_int), ("tP", c_int),
         ("rows_per_group", c_int), ("act", c_int), ("c_acc", c_float), ("c_r1", c_float), ("c_r2", c_float),
         ("r1_lo", c_void_p), ("r2_lo", c_void_p), ("out_lo", c_void_p), ("conv_shift", c_int),
+    ]
+
+
+class FfArgs(ctypes.Structure):
+    """struct ew_ff_args (include/evoworld_hip.h)."""
+    _fields_ = [
+        ("x", c_void_p), ("w1p", c_void_p), ("b1p", c_void_p), ("w2p", c_void_p), ("b2", c_void_p), ("rowbias", c_void_p),
+        ("r1", c_void_p), ("r1_lo", c_void_p), ("r2", c_void_p), ("r2_lo", c_void_p), ("out", c_void_p), ("out_lo", c_void_p),
+        ("zero_page", c_void_p), ("M", c_int), ("C", c_int), ("hidden", c_int), ("rows_per_group", c_int), ("ld_rowbias", c_int),
+        ("c_acc", c_float), ("c_r1", c_float), ("c_r2", c_float),
     ]
 
 
@@ -72,6 +82,7 @@ def load():
         "ew_groupnorm_finalize": [P, I, I, I, I, P],
         "ew_groupnorm_apply_f16": [P, P, P, P, P, P, I, I, I, I, I, I, F, I, P],
         "ew_gemm_streamk_init": [P],
+        "ew_ff_geglu320_f16": [ctypes.POINTER(FfArgs), P],
         "ew_layernorm_f16": [P, P, P, I, P, P, P, P, P, I, I, F, P],
         "ew_attn_spatial_f16": [P, P, P, P, I, I, I, I, LL, I, F, P],
         "ew_attn_temporal_f16": [P, P, P, P, I, I, I, I, I, I, F, P],

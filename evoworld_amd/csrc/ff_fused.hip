@@ -1,0 +1,361 @@
+// ff_fused.hip -- fused GEGLU feed-forward for the 320-channel (level 0) transformer blocks, gfx950 (round 3).
+//
+//   out = c_acc * ( GEGLU(x W1^T + b1) W2^T + b2 + rowbias ) + c_r1 * r1 + c_r2 * r2        x: [M, 320] fp16 (LayerNorm output)
+//
+// i.e. diffusers FeedForward(dim, activation_fn="geglu") = net.0 (GEGLU proj 320 -> 2 x 1280) + net.2 (Linear 1280 -> 320) of
+// BasicTransformerBlock.ff / TemporalBasicTransformerBlock.ff / .ff_in (instantiated through evoworld/trainer/unet_plucker.py:
+// 161-233), with the residual / AlphaBlender epilogue of ew_gemm_f16.
+//
+// Why a fused kernel: as two GEMMs the 1280-wide GEGLU intermediate of level 0 (460800 x 1280 fp16 = 1.18 GB) is written and
+// read back 15 times per forward; the pair is 11 % of the forward and runs at 860 TF/s.  Here it never leaves the chip:
+//   * one workgroup = 4 waves, ONE wave per SIMD with the whole 512-entry register file (accumulators in the accumulation
+//     half): a wave owns 32 rows of a 128-row tile -- their x fragments (80 registers) stay resident for the whole tile, the
+//     down-projection accumulator 32 x 320 (160 registers) too;
+//   * the hidden dimension is walked in 40 chunks of 32: up-projection of the chunk (value + gate columns: a 32 x 64
+//     accumulator, K = 320, 80 MFMAs) -> bias + value * gelu(gate) in registers -> the result IS the A fragment of the
+//     down-projection's k-step (the host packs W1's rows so that the four outputs a lane owns per fragment pair are consecutive
+//     hidden indices) -> 40 MFMAs into the 32 x 320 accumulator.  No LDS round trip for the intermediate, no second pass over x;
+//   * only the weights go through LDS, one chunk image (W1 40 KB + W2 20 KB) per step, double-buffered, by LDS-DMA from
+//     host-packed images that are byte copies of the LDS layout (every DMA instruction reads 1 KB contiguous; the 16-byte-slot
+//     XOR swizzles that make the ds_read_b128 fragment reads conflict-free are baked into the pack).  One barrier per chunk: a
+//     chunk's image is requested a whole chunk (120 MFMAs per wave) before it is needed.  2.4 MB of weights are shared by all 256
+//     workgroups walking them in step: L2-resident.
+//   * the epilogue is the LDS-free "direct" form of gemm3_f16.hip (W2's rows are staged permuted so that a lane's accumulator
+//     pair is 8 consecutive output columns: 16-byte accesses for bias / row-bias / residual hi / output hi, 8-byte for lo8).
+// Same rounding points as the two-GEMM path (fp32 accumulation, GEGLU in fp32, intermediate rounded to fp16 once, fp32
+// accumulation, output split or fp16): results agree to fp32 summation order.
+#include "gemm_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int C = 320, HID = 1280, CH = 32, NCH = HID / CH;       // 40 chunks of 32 hidden units
+constexpr int BM = 128, WROWS = 32, NWV = 4;                      // 4 waves x 32 rows
+constexpr int KS = C / 32;                                         // 10 k-steps of the up-projection
+constexpr int KT = C / 64;                                         // W1 chunk image = 5 K-tiles of [64 staged rows][64 k]
+constexpr int W1_KT = 64 * 128;                                    // 8 KB
+constexpr int W1_TILE = KT * W1_KT;                                // 40 KB per chunk
+constexpr int W2_TILE = C * CH * 2;                                // 320 staged rows x 32 k x 2 B = 20 KB per chunk
+constexpr int LDS_W1 = 0, LDS_W2 = 2 * W1_TILE, LDS_B1 = LDS_W2 + 2 * W2_TILE;   // both double-buffered by chunk
+constexpr int LDS_BYTES = LDS_B1 + 2 * HID * 2;                    // 80 + 40 + 5 KB
+constexpr int P1 = W1_TILE / 1024 / NWV, P2 = W2_TILE / 1024 / NWV;   // DMA pieces per wave and chunk: 10 / 5
+
+struct FfP {
+    const f16* x;
+    const f16* w1p;
+    const f16* b1p;
+    const f16* w2p;
+    const f16* b2;
+    const f16* rowbias;
+    const f16* r1;
+    const f16* r2;
+    const int8_t* r1_lo;
+    const int8_t* r2_lo;
+    f16* out;
+    int8_t* out_lo;
+    const f16* zero_page;
+    int M, rows_per_group, ld_rowbias, n_tiles;
+    float c_acc, c_r1, c_r2;
+};
+
+#define FF_FENCE() asm volatile("" ::: "memory")
+// vmcnt(0) through the builtin (simm16: vmcnt = 0, expcnt = 7, lgkmcnt = 15), not inline asm: hipcc's waitcnt pass then KNOWS the
+// queue is empty.  With an opaque asm wait it kept a vmcnt(0) in front of the first use of the x fragments in EVERY chunk (their
+// loads are issued at the end of the previous tile), which drained the weight DMA right after it was requested: 3.4x slower.
+#define FF_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
+
+template <bool LO, bool R2>
+__global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fks = lane >> 4, sw = frow & 7;
+
+    // W2 buffers start as zeros: the first chunk of a tile runs the trailing down-projection slot on a zero A fragment (no
+    // branch in the pipeline), which must not meet NaN bit patterns of uninitialised LDS (later tiles find old weights there)
+    for (int i = tid; i < 2 * W2_TILE / 16; i += 64 * NWV) *(f16x8*)(smem + LDS_W2 + i * 16) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    // packed b1 -> LDS once (5 KB)
+    for (int i = tid; i < 2 * HID * 2 / 16; i += 64 * NWV) *(f16x8*)(smem + LDS_B1 + i * 16) = *(const f16x8*)((const char*)p.b1p + i * 16);
+
+    const int G = gridDim.x;
+    const int n_my = (p.n_tiles - (int)blockIdx.x + G - 1) / G;            // tiles blockIdx.x, +G, ...
+    if (n_my <= 0) return;
+
+    const int CC_total = n_my * NCH;
+    // ---- weight DMA stream: global chunk cc <-> W1 / W2 chunk images (cc mod 40), identical for every tile; buffers cc & 1
+    // prologue: chunk 0 and chunk 1 (W1: ring of 2 by chunk; W2: ring of 2, one chunk behind -- see the hand-over below)
+    auto issue_w1 = [&](int c_mod, int slot) __attribute__((always_inline)) {
+        const f16* s1 = (const f16*)((const char*)p.w1p + (size_t)c_mod * W1_TILE + wave * (P1 * 1024)) + lane * 8;
+        char* d1 = smem + LDS_W1 + slot * W1_TILE + wave * (P1 * 1024);
+#pragma unroll
+        for (int k = 0; k < P1; ++k) glds16(s1 + k * 512, d1 + k * 1024);
+    };
+    auto issue_w2 = [&](int c_mod, int slot) __attribute__((always_inline)) {
+        const f16* s2 = (const f16*)((const char*)p.w2p + (size_t)c_mod * W2_TILE + wave * (P2 * 1024)) + lane * 8;
+        char* d2 = smem + LDS_W2 + slot * W2_TILE + wave * (P2 * 1024);
+#pragma unroll
+        for (int k = 0; k < P2; ++k) glds16(s2 + k * 512, d2 + k * 1024);
+    };
+    issue_w1(0, 0);
+    int cc = 0;                                 // global chunk index
+    __syncthreads();                            // b1 staged; W1(0) landed (the barrier's fence drains the DMA queue)
+    if (CC_total > 1) issue_w1(1, 1);
+
+    // fragment read offsets.  W1 K-tile image: staged row R = j*16 + frow (128-byte rows), 16-byte k-slot ks in 0..7 ->
+    // R*128 + ((ks ^ (R & 7)) << 4); W2 chunk image: staged row R = jj*16 + frow (64-byte rows), k-slot ks in 0..3 ->
+    // R*64 + ((ks ^ g((R >> 2) & 3)) << 4), g = {0, 2, 3, 1}: four rows share a 256-byte bank row, and the 16 lanes a
+    // ds_read_b128 services together are (fks, rows 0-3 | 12-15) + (fks+1, rows 4-11) -- g makes their 16 slots distinct
+    int rd1[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) rd1[h] = frow * 128 + (((h * 4 + fks) ^ sw) << 4);
+    const int gq = (0x78 >> (2 * ((frow >> 2) & 3))) & 3;             // {0, 2, 3, 1}[(frow >> 2) & 3]
+    const int rd2 = frow * 64 + ((fks ^ gq) << 4);
+#define FF_W1F(buf, ks_, j_) (*(const f16x8*)((buf) + ((ks_) >> 1) * W1_KT + (j_) * 2048 + rd1[(ks_) & 1]))
+#define FF_PIN() __builtin_amdgcn_sched_barrier(0)
+
+    // W1 fragment ring: k-step ks uses wf[ks % 3]; the fragments of ks+2 are read while ks is multiplied; the first two sets of
+    // a chunk are read during the second phase of the PREVIOUS chunk.
+    f16x8 wf[3][4];
+    {
+        const char* w1b = smem + LDS_W1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { wf[0][j] = FF_W1F(w1b, 0, j); wf[1][j] = FF_W1F(w1b, 1, j); }
+    }
+
+    // ---- x fragments of this wave's 32 rows of a tile: row frow (+16 rf), k = ks*32 + fks*8 .. +8.  The NEXT tile's fragments
+    // are requested before the epilogue of the current one (the registers are free once the last up-projection is done), so
+    // their HBM latency is covered by the epilogue.
+    f16x8 xf[2][KS];
+    auto load_x = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int rf = 0; rf < 2; ++rf) {
+            const int m = min(tile * BM + wave * WROWS + rf * 16 + frow, p.M - 1);
+            const f16* xp = p.x + (size_t)m * C + fks * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) xf[rf][ks] = *(const f16x8*)(xp + ks * 32);
+        }
+    };
+    load_x((int)blockIdx.x);
+
+    for (int ti = 0; ti < n_my; ++ti) {
+        const int tile = (int)blockIdx.x + ti * G;
+        const int m_w0 = tile * BM + wave * WROWS;
+        f32x4 acc2[2][C / 16];
+#pragma unroll
+        for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+            for (int jj = 0; jj < C / 16; ++jj) acc2[rf][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f16x8 hf_old[2] = {};                   // GEGLU output of the previous chunk (A fragment of its down-projection k-step)
+
+        // Software pipeline over the chunks of the tile.  Iteration c:
+        //   phase 1: up-projection of chunk c (80 MFMAs; W1 fragments two k-steps ahead)
+        //   hand-over barrier: W1 buffer cc & 1 and W2 buffer cc & 1 (down-projection of chunk c-2 is done) are free; this
+        //            wave's pieces of W1(cc+1) and W2(cc-1), requested a chunk ago, have landed
+        //   phase 2: GEGLU of chunk c (VALU) interleaved with the down-projection of chunk c-1 (40 MFMAs) and with the DMA
+        //            requests for W1(cc+2) / W2(cc): the VALU slices and the DMA issue run while the MFMA pipe drains
+        // The down-projection therefore trails by one chunk; it is flushed after the last chunk of the tile.
+        for (int c = 0; c < NCH; ++c, ++cc) {
+            const char* w1b = smem + LDS_W1 + (cc & 1) * W1_TILE;
+            const char* w1n = smem + LDS_W1 + ((cc + 1) & 1) * W1_TILE;
+            const char* w2b = smem + LDS_W2 + ((cc + 1) & 1) * W2_TILE;       // W2(cc - 1)
+            f32x4 acc1[2][4];
+#pragma unroll
+            for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc1[rf][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 2 < KS) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wf[(ks + 2) % 3][j] = FF_W1F(w1b, ks + 2, j);
+                }
+                FF_PIN();
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rf = 0; rf < 2; ++rf)
+                        acc1[rf][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks % 3][j], xf[rf][ks], acc1[rf][j], 0, 0, 0);
+                FF_PIN();
+            }
+            FF_WAIT_VM0();
+            FF_FENCE();
+            __builtin_amdgcn_s_barrier();
+            FF_FENCE();
+            // ---- phase 2
+            // (no branches in this phase: on the first chunk of a tile hf_old is zero, and past the end of the block's work the W1
+            // request / fragment reads touch buffers nobody reads again)
+            f16x8 w2f[2][5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) w2f[0][u] = *(const f16x8*)(w2b + u * 1024 + rd2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wf[0][j] = FF_W1F(w1n, 0, j); wf[1][j] = FF_W1F(w1n, 1, j); }
+            // DMA requests of this hand-over: W1(cc+2) -> buffer cc & 1 (10 pieces per wave), W2(cc) -> buffer cc & 1 (5 pieces)
+            int c2 = c + 2;
+            c2 = c2 >= NCH ? c2 - NCH : c2;
+            const f16* s1 = (const f16*)((const char*)p.w1p + (size_t)c2 * W1_TILE + wave * (P1 * 1024)) + lane * 8;
+            char* d1 = smem + LDS_W1 + (cc & 1) * W1_TILE + wave * (P1 * 1024);
+            const f16* s2 = (const f16*)((const char*)p.w2p + (size_t)c * W2_TILE + wave * (P2 * 1024)) + lane * 8;
+            char* d2 = smem + LDS_W2 + (cc & 1) * W2_TILE + wave * (P2 * 1024);
+            f16x8 hf[2];
+            const char* bb = smem + LDS_B1 + (c * 64 + fks * 4) * 2;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                // GEGLU slice g4 = (h, rf): fragment pair (value 2h, gate 2h+1) -> hidden 8 fks + 4h + e of the chunk
+                {
+                    const int h = g4 >> 1, rf = g4 & 1;
+                    const f16x4 bv = *(const f16x4*)(bb + (2 * h) * 32), bg = *(const f16x4*)(bb + (2 * h + 1) * 32);
+                    const f32x4 va = acc1[rf][2 * h] + (f32x4){(float)bv[0], (float)bv[1], (float)bv[2], (float)bv[3]};
+                    const f32x4 gg = acc1[rf][2 * h + 1] + (f32x4){(float)bg[0], (float)bg[1], (float)bg[2], (float)bg[3]};
+                    const f32x2 o01 = ew_vgelu2((f32x2){va[0], va[1]}, (f32x2){gg[0], gg[1]});
+                    const f32x2 o23 = ew_vgelu2((f32x2){va[2], va[3]}, (f32x2){gg[2], gg[3]});
+                    hf[rf][4 * h + 0] = (f16)o01[0];
+                    hf[rf][4 * h + 1] = (f16)o01[1];
+                    hf[rf][4 * h + 2] = (f16)o23[0];
+                    hf[rf][4 * h + 3] = (f16)o23[1];
+                }
+                if (g4 + 1 < 4) {
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) w2f[(g4 + 1) & 1][u] = *(const f16x8*)(w2b + ((g4 + 1) * 5 + u) * 1024 + rd2);
+                }
+                FF_PIN();
+#pragma unroll
+                for (int u = 0; u < 5; ++u)
+#pragma unroll
+                    for (int rf = 0; rf < 2; ++rf)
+                        acc2[rf][g4 * 5 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[g4 & 1][u], hf_old[rf], acc2[rf][g4 * 5 + u], 0, 0, 0);
+                FF_PIN();
+                // DMA pieces: 4 per group (W1 pieces 0..9, then W2 pieces 0..4; the last group has 3)
+#pragma unroll
+                for (int k = g4 * 4; k < g4 * 4 + 4 && k < P1 + P2; ++k) {
+                    if (k < P1) glds16(s1 + k * 512, d1 + k * 1024);
+                    else glds16(s2 + (k - P1) * 512, d2 + (k - P1) * 1024);
+                }
+                FF_PIN();
+            }
+            hf_old[0] = hf[0];
+            hf_old[1] = hf[1];
+        }
+        // ---- flush: down-projection of the tile's last chunk (its W2 image was requested in the last phase 2)
+        {
+            FF_WAIT_VM0();
+            FF_FENCE();
+            __builtin_amdgcn_s_barrier();
+            FF_FENCE();
+            const char* w2b = smem + LDS_W2 + ((cc + 1) & 1) * W2_TILE;       // W2(cc - 1): cc already points past the tile
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f16x8 w2f[5];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) w2f[u] = *(const f16x8*)(w2b + (g4 * 5 + u) * 1024 + rd2);
+#pragma unroll
+                for (int u = 0; u < 5; ++u)
+#pragma unroll
+                    for (int rf = 0; rf < 2; ++rf)
+                        acc2[rf][g4 * 5 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[u], hf_old[rf], acc2[rf][g4 * 5 + u], 0, 0, 0);
+            }
+        }
+        if (ti + 1 < n_my) load_x(tile + G);
+        // ---- epilogue: lane (frow, fks) owns, for pair q, the 8 output columns q*32 + fks*8 .. +8 of rows frow, frow + 16.  With
+        // one wave per SIMD nothing else hides memory latency, so ALL residual operands of a row fragment (10 steps: 60 / 120
+        // registers) are requested before the first one is used: two round trips to HBM per tile instead of twenty.
+        {
+            const f16* rbp = p.rowbias ? p.rowbias : p.zero_page;
+            const f16* r1p = p.r1 ? p.r1 : p.zero_page;
+            const f16* r2p = p.r2 ? p.r2 : p.zero_page;
+            const int8_t* r1lp = p.r1_lo ? p.r1_lo : (const int8_t*)p.zero_page;
+            const int8_t* r2lp = p.r2_lo ? p.r2_lo : (const int8_t*)p.zero_page;
+            const int mrb = p.rowbias ? 1 : 0, m1 = p.r1 ? 1 : 0, m2 = p.r2 ? 1 : 0, m1l = p.r1_lo ? 1 : 0, m2l = p.r2_lo ? 1 : 0;
+            constexpr int NQ = C / 32;
+#pragma unroll
+            for (int rf = 0; rf < 2; ++rf) {
+                const int m = m_w0 + rf * 16 + frow;
+                const int mc = min(m, p.M - 1);
+                const int g = mc / p.rows_per_group;
+                f16x8 q1v[NQ], q2v[NQ];
+                u32x2 q1l[NQ], q2l[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int n = q * 32 + fks * 8;
+                    q1v[q] = *(const f16x8*)(r1p + ((size_t)mc * C + n) * m1);
+                    if (LO) q1l[q] = *(const u32x2*)(r1lp + ((size_t)mc * C + n) * m1l);
+                    if (R2) {
+                        q2v[q] = *(const f16x8*)(r2p + ((size_t)mc * C + n) * m2);
+                        if (LO) q2l[q] = *(const u32x2*)(r2lp + ((size_t)mc * C + n) * m2l);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int n = q * 32 + fks * 8;
+                    const f16x8 bvv = *(const f16x8*)(p.b2 + n);
+                    const f16x8 rbv = *(const f16x8*)(rbp + (size_t)(g * p.ld_rowbias + n) * mrb);
+                    const f32x4 a0 = acc2[rf][2 * q], a1 = acc2[rf][2 * q + 1];
+                    const float vv[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    f16x8 o;
+                    int s8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float xv = (vv[e] + (float)bvv[e] + (float)rbv[e]) * p.c_acc;
+                        if (LO) xv += p.c_r1 * ew_split_dec(q1v[q][e], ew_sbyte(q1l[q][e >> 2], e & 3));
+                        else xv += p.c_r1 * (float)q1v[q][e];
+                        if (R2) {
+                            if (LO) xv += p.c_r2 * ew_split_dec(q2v[q][e], ew_sbyte(q2l[q][e >> 2], e & 3));
+                            else xv += p.c_r2 * (float)q2v[q][e];
+                        }
+                        o[e] = (f16)xv;
+                        s8[e] = ew_split_enc(xv, o[e]);
+                    }
+                    if (m < p.M) {
+                        *(f16x8*)(p.out + (size_t)m * C + n) = o;
+                        if (LO && p.out_lo)
+                            *(u32x2*)(p.out_lo + (size_t)m * C + n) = (u32x2){ew_pack4(s8[0], s8[1], s8[2], s8[3]), ew_pack4(s8[4], s8[5], s8[6], s8[7])};
+                    }
+                }
+            }
+        }
+        FF_WAIT_VM0();      // next tile's x fragments (and this tile's stores) are complete before the chunk loop starts
+    }
+    FF_WAIT_VM0();          // the last hand-overs requested images nobody reads: let them land
+}
+
+}  // namespace
+
+// Host-side layout contract of the packs (evoworld_amd/ops.py: ff_pack builds them with torch index ops):
+//   w1p  [40 chunks][5 K-tiles][64 staged rows][8 slots][8 halves]: staged row r = 16 j + i, j = 2h + vg (vg: 0 value, 1 gate),
+//        i = 4 fks + e  <-  proj row (vg ? HID : 0) + 32 c + 8 fks + 4 h + e;   slot sl holds k = 64 kt + 8 (sl ^ (r & 7)) .. +8
+//   b1p  [40][64] in the same staged-row order
+//   w2p  [40 chunks][320 staged rows][4 slots][8 halves]: staged row r = 16 jj + i  <-  output channel (jj >> 1) * 32 + (i >> 2) * 8 +
+//        (jj & 1) * 4 + (i & 3);   slot sl holds hidden k = 32 c + 8 (sl ^ g((r >> 2) & 3)), g = {0, 2, 3, 1} .. +8
+extern "C" ew_status ew_ff_geglu320_f16(const ew_ff_args* a, void* stream) {
+    EW_REQUIRE(a != nullptr, "ew_ff_geglu320_f16: null args");
+    EW_REQUIRE(a->x && a->w1p && a->b1p && a->w2p && a->b2 && a->out && a->zero_page, "ew_ff_geglu320_f16: null pointer");
+    EW_REQUIRE(a->C == C && a->hidden == HID, "ew_ff_geglu320_f16: built for C = 320, hidden = 1280 (got %d, %d)", a->C, a->hidden);
+    EW_REQUIRE(a->M > 0 && a->rows_per_group >= 1, "ew_ff_geglu320_f16: bad M / rows_per_group");
+    EW_REQUIRE(!a->rowbias || a->ld_rowbias % 8 == 0, "ew_ff_geglu320_f16: ld_rowbias must be a multiple of 8");
+    EW_REQUIRE((!a->r1_lo || a->r1) && (!a->r2_lo || a->r2), "ew_ff_geglu320_f16: r1_lo / r2_lo need r1 / r2");
+    EW_REQUIRE((long long)a->M * C * 2 < (1LL << 40), "ew_ff_geglu320_f16: M too large");
+    FfP p;
+    p.x = (const f16*)a->x; p.w1p = (const f16*)a->w1p; p.b1p = (const f16*)a->b1p; p.w2p = (const f16*)a->w2p; p.b2 = (const f16*)a->b2;
+    p.rowbias = (const f16*)a->rowbias; p.r1 = (const f16*)a->r1; p.r2 = (const f16*)a->r2;
+    p.r1_lo = (const int8_t*)a->r1_lo; p.r2_lo = (const int8_t*)a->r2_lo; p.out = (f16*)a->out; p.out_lo = (int8_t*)a->out_lo;
+    p.zero_page = (const f16*)a->zero_page;
+    p.M = a->M; p.rows_per_group = a->rows_per_group; p.ld_rowbias = a->rowbias ? a->ld_rowbias : 0;
+    p.n_tiles = ew_cdiv(a->M, BM);
+    p.c_acc = a->c_acc; p.c_r1 = a->r1 ? a->c_r1 : 0.f; p.c_r2 = a->r2 ? a->c_r2 : 0.f;
+    const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
+    const bool lo = a->r1_lo || a->r2_lo || a->out_lo;
+    const bool r2 = a->r2 != nullptr;
+    hipStream_t s = (hipStream_t)stream;
+#define FF_LAUNCH(LO_, R2_)                                                                                                \
+    do {                                                                                                                   \
+        static std::atomic<unsigned long long> mask{0};                                                                    \
+        if (ew_status st = ew_ensure_dynamic_lds((const void*)ff320_kernel<LO_, R2_>, LDS_BYTES, mask)) return st;         \
+        hipLaunchKernelGGL((ff320_kernel<LO_, R2_>), dim3(grid), dim3(64 * NWV), LDS_BYTES, s, p);                         \
+    } while (0)
+    if (lo && r2) FF_LAUNCH(true, true);
+    else if (lo) FF_LAUNCH(true, false);
+    else if (r2) FF_LAUNCH(false, true);
+    else FF_LAUNCH(false, false);
+#undef FF_LAUNCH
+    return ew_check_launch("ew_ff_geglu320_f16");
+}

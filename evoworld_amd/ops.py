@@ -457,6 +457,57 @@ def gemm_fp8(a, a_scale, w, w_scale, out=None):
     return out
 
 
+def ff_pack(w1, b1, w2):
+    """Weights of one GEGLU feed-forward (w1 [2*H, C] value rows then gate rows, b1 [2*H], w2 [C, H]; fp32 or fp16, on the
+    device) -> (w1p, b1p, w2p) fp16 in the LDS-image packs ew_ff_geglu320_f16 streams (layout: csrc/ff_fused.hip)."""
+    dev = w1.device
+    H2, C = w1.shape
+    H = H2 // 2
+    assert C == 320 and H == 1280 and tuple(w2.shape) == (C, H)
+    nch = H // 32
+    c = torch.arange(nch, device=dev)[:, None]
+    r = torch.arange(64, device=dev)[None, :]
+    j, i = r // 16, r % 16
+    hh, vg = j // 2, j % 2
+    src = vg * H + 32 * c + 8 * (i // 4) + 4 * hh + (i % 4)                                 # [nch, 64] proj rows
+    sl = torch.arange(8, device=dev)
+    w1g = w1.float()[src.reshape(-1)].reshape(nch, 64, C // 64, 8, 8)                       # [c, r, kt, slot, 8]
+    perm1 = (sl[None, :] ^ (torch.arange(64, device=dev)[:, None] & 7))                     # packed slot sl <- k-slot sl ^ (r & 7)
+    w1g = torch.gather(w1g, 3, perm1[None, :, None, :, None].expand(nch, 64, C // 64, 8, 8))
+    w1p = w1g.permute(0, 2, 1, 3, 4).contiguous().to(torch.float16)                         # [c, kt, r, slot, 8]
+    b1p = b1.float()[src.reshape(-1)].to(torch.float16).contiguous()
+    r2 = torch.arange(C, device=dev)
+    jj, i2 = r2 // 16, r2 % 16
+    col = (jj // 2) * 32 + (i2 // 4) * 8 + (jj % 2) * 4 + (i2 % 4)                          # staged row -> output channel
+    w2g = w2.float()[col].reshape(C, nch, 4, 8)                                              # [r, c, slot, 8]
+    gq = torch.tensor([0, 2, 3, 1], device=dev)[(r2 >> 2) & 3]                              # bank-conflict-free slot XOR per row
+    perm2 = (torch.arange(4, device=dev)[None, :] ^ gq[:, None])
+    w2g = torch.gather(w2g, 2, perm2[:, None, :, None].expand(C, nch, 4, 8))
+    w2p = w2g.permute(1, 0, 2, 3).contiguous().to(torch.float16)                             # [c, r, slot, 8]
+    return w1p, b1p, w2p
+
+
+def ff_geglu320(x, pack, b2, out, *, rowbias=None, rows_per_group=1, ld_rowbias=None, r1=None, r2=None, c_acc=1.0, c_r1=1.0, c_r2=1.0):
+    """out = c_acc * (GEGLU(x W1^T + b1) W2^T + b2 + rowbias) + c_r1 * r1 + c_r2 * r2 for 320-channel tokens, one kernel
+    (ew_ff_geglu320_f16): x fp16 [M, 320]; pack = ff_pack(...); r1 / r2 / out tensors or `Res`."""
+    lib = _lib.load()
+    _req(x, torch.float16, "x")
+    a = _lib.FfArgs()
+    r1h, r1l = _hl(r1)
+    r2h, r2l = _hl(r2)
+    oh, ol = _hl(out)
+    w1p, b1p, w2p = pack
+    a.x, a.w1p, a.b1p, a.w2p, a.b2, a.rowbias = _ptr(x), _ptr(w1p), _ptr(b1p), _ptr(w2p), _ptr(b2), _ptr(rowbias)
+    a.r1, a.r1_lo, a.r2, a.r2_lo, a.out, a.out_lo = _ptr(r1h), _ptr(r1l), _ptr(r2h), _ptr(r2l), _ptr(oh), _ptr(ol)
+    a.zero_page = _ptr(zero_page(x.device))
+    a.M, a.C, a.hidden = x.shape[0], x.shape[1], w2p.shape[0] * 32
+    a.rows_per_group = rows_per_group
+    a.ld_rowbias = ld_rowbias if ld_rowbias is not None else x.shape[1]
+    a.c_acc, a.c_r1, a.c_r2 = c_acc, c_r1, c_r2
+    _lib.check(lib.ew_ff_geglu320_f16(ctypes.byref(a), _stream()), "ew_ff_geglu320_f16")
+    return out
+
+
 def pack_conv_weight(w, cpad=None):
     """[O, I, *taps] (Conv2d 3x3 / Conv3d (3,1,1)) fp32 -> fp16 [O, K] in the K order ew_gemm_f16's conv modes read:
     [I/64 chunks][taps][64 channels].  `cpad` zero-pads the input channels first (conv_in: 18 -> 64)."""

@@ -114,6 +114,33 @@ int ew_gemm_streamk_status(void);
  * captured launch on a stream without a workspace runs the whole-tile schedule instead. */
 ew_status ew_gemm_streamk_init(void* stream);
 
+/* Fused GEGLU feed-forward for 320-channel tokens (ABI 5; level 0 of the U-Net: 460800 tokens per forward, 15 feed-forwards):
+ *   out = c_acc * (GEGLU(x W1^T + b1) W2^T + b2 + rowbias[m / rows_per_group]) + c_r1 * r1 + c_r2 * r2
+ * = diffusers FeedForward(320, activation_fn="geglu") (net.0 GEGLU projection 320 -> 2 x 1280, net.2 Linear 1280 -> 320) of
+ * BasicTransformerBlock.ff / TemporalBasicTransformerBlock.ff_in / .ff (instantiated via evoworld/trainer/unet_plucker.py:161-233)
+ * with the residual / AlphaBlender epilogue of ew_gemm_f16; the 1280-wide intermediate never goes to HBM.  x: fp16 [M, 320]
+ * (the LayerNorm output); w1p / b1p / w2p: the weights in the kernel's LDS-image packs (layout: csrc/ff_fused.hip, built by
+ * evoworld_amd.ops.ff_pack); b2 fp16 [320]; r1 / r2 / out [M, 320] with optional lo8 companions as in ew_gemm_args. */
+typedef struct ew_ff_args {
+    const void* x;
+    const void* w1p;
+    const void* b1p;
+    const void* w2p;
+    const void* b2;
+    const void* rowbias;   /* fp16 [G, ld_rowbias] or NULL */
+    const void* r1;
+    const void* r1_lo;
+    const void* r2;
+    const void* r2_lo;
+    void* out;
+    void* out_lo;
+    const void* zero_page;
+    int M, C, hidden;      /* C = 320, hidden = 1280 */
+    int rows_per_group, ld_rowbias;
+    float c_acc, c_r1, c_r2;
+} ew_ff_args;
+ew_status ew_ff_geglu320_f16(const ew_ff_args* args, void* stream);
+
 /* GroupNorm statistics + apply, channels-last fp16, over a (virtual) channel concat.
  * The normalised tensor has C_tot channels in `groups` groups; a stats/apply call handles the C_src channels
  * [c_off, c_off+C_src) that live in tensor `x` ([n_slabs*rows, C_src]); a skip-concat input is covered by
