@@ -47,6 +47,8 @@ class FfArgs(ctypes.Structure):
         ("r1", c_void_p), ("r1_lo", c_void_p), ("r2", c_void_p), ("r2_lo", c_void_p), ("out", c_void_p), ("out_lo", c_void_p),
         ("zero_page", c_void_p), ("M", c_int), ("C", c_int), ("hidden", c_int), ("rows_per_group", c_int), ("ld_rowbias", c_int),
         ("c_acc", c_float), ("c_r1", c_float), ("c_r2", c_float),
+        ("x_lo", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("addvec", c_void_p), ("add_rows_per_group", c_int),
+        ("ln_eps", c_float),
     ]
 
 

@@ -54,8 +54,12 @@ struct FfP {
     f16* out;
     int8_t* out_lo;
     const f16* zero_page;
-    int M, rows_per_group, ld_rowbias, n_tiles;
-    float c_acc, c_r1, c_r2;
+    const int8_t* x_lo;      // LayerNorm prologue (ln_gamma != null): x is the stream (hi + optional lo8), + addvec[m / add_rpg] before the norm
+    const f16* ln_gamma;
+    const f16* ln_beta;
+    const f16* addvec;
+    int M, rows_per_group, ld_rowbias, n_tiles, add_rpg;
+    float c_acc, c_r1, c_r2, ln_eps;
 };
 
 #define FF_FENCE() asm volatile("" ::: "memory")
@@ -64,7 +68,7 @@ struct FfP {
 // loads are issued at the end of the previous tile), which drained the weight DMA right after it was requested: 3.4x slower.
 #define FF_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
 
-template <bool LO, bool R2>
+template <bool LO, bool R2, bool XLO>
 __global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -113,6 +117,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
     const int rd2 = frow * 64 + ((fks ^ gq) << 4);
 #define FF_W1F(buf, ks_, j_) (*(const f16x8*)((buf) + ((ks_) >> 1) * W1_KT + (j_) * 2048 + rd1[(ks_) & 1]))
 #define FF_PIN() __builtin_amdgcn_sched_barrier(0)
+#ifndef FF_ABL
+#define FF_ABL 0          /* ablation builds (tools/experiments): 1 no GEGLU math, 2 no DMA, 4 no epilogue, 8 no up-proj MFMA, 16 no down-proj MFMA */
+#endif
 
     // W1 fragment ring: k-step ks uses wf[ks % 3]; the fragments of ks+2 are read while ks is multiplied; the first two sets of
     // a chunk are read during the second phase of the PREVIOUS chunk.
@@ -127,6 +134,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
     // are requested before the epilogue of the current one (the registers are free once the last up-projection is done), so
     // their HBM latency is covered by the epilogue.
     f16x8 xf[2][KS];
+    u32x2 xl[2][XLO ? KS : 1];                 // lo8 companions of the LayerNorm input stream
     auto load_x = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
         for (int rf = 0; rf < 2; ++rf) {
@@ -134,13 +142,74 @@ __global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
             const f16* xp = p.x + (size_t)m * C + fks * 8;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) xf[rf][ks] = *(const f16x8*)(xp + ks * 32);
+            if constexpr (XLO) {
+                const int8_t* lp = p.x_lo + (size_t)m * C + fks * 8;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) xl[rf][ks] = *(const u32x2*)(lp + ks * 32);
+            }
+        }
+    };
+    // LayerNorm prologue, in place on the fragments (torch.nn.LayerNorm of BasicTransformerBlock.norm3 / TemporalBasicTransformerBlock
+    // .norm_in / .norm3; same arithmetic as ew_layernorm_f16: fp32 two-pass mean / variance over the decoded stream values (+ the
+    // per-frame add vector), ((v - mean) * rstd) * gamma + beta rounded to fp16).  A row's 320 values sit in the 4 lanes
+    // (frow, fks = 0..3) x 10 fragments x 8: the values are re-decoded in each pass instead of being kept in fp32.
+    auto ln_x = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int rf = 0; rf < 2; ++rf) {
+            const int m = min(tile * BM + wave * WROWS + rf * 16 + frow, p.M - 1);
+            const f16* ap = p.addvec ? p.addvec + (size_t)(m / p.add_rpg) * C + fks * 8 : p.zero_page;
+            const int ma = p.addvec ? 1 : 0;
+            auto val = [&](int ks, float (&v)[8]) __attribute__((always_inline)) {
+                const f16x8 av = *(const f16x8*)(ap + ks * 32 * ma);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t;
+                    if constexpr (XLO) t = ew_split_dec(xf[rf][ks][e], ew_sbyte(xl[rf][ks][e >> 2], e & 3));
+                    else t = (float)xf[rf][ks][e];
+                    v[e] = t + (float)av[e];
+                }
+            };
+            float sum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                float v[8];
+                val(ks, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += v[e];
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float mean = sum * (1.0f / C);
+            float sq = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                float v[8];
+                val(ks, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; sq = fmaf(d, d, sq); }
+            }
+            sq += __shfl_xor(sq, 16, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            const float rstd = rsqrtf(sq * (1.0f / C) + p.ln_eps);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                float v[8];
+                val(ks, v);
+                const f16x8 gm = *(const f16x8*)(p.ln_gamma + ks * 32 + fks * 8), bt = *(const f16x8*)(p.ln_beta + ks * 32 + fks * 8);
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)((v[e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
+                xf[rf][ks] = o;
+            }
         }
     };
     load_x((int)blockIdx.x);
+    FF_WAIT_VM0();
 
     for (int ti = 0; ti < n_my; ++ti) {
         const int tile = (int)blockIdx.x + ti * G;
         const int m_w0 = tile * BM + wave * WROWS;
+        if (p.ln_gamma) ln_x(tile);
         f32x4 acc2[2][C / 16];
 #pragma unroll
         for (int rf = 0; rf < 2; ++rf)
@@ -175,7 +244,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int rf = 0; rf < 2; ++rf)
+#if FF_ABL & 8
+                        asm volatile("" ::"v"(wf[ks % 3][j]), "v"(xf[rf][ks]));
+#else
                         acc1[rf][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks % 3][j], xf[rf][ks], acc1[rf][j], 0, 0, 0);
+#endif
                 FF_PIN();
             }
             FF_WAIT_VM0();
@@ -207,8 +280,13 @@ __global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
                     const f16x4 bv = *(const f16x4*)(bb + (2 * h) * 32), bg = *(const f16x4*)(bb + (2 * h + 1) * 32);
                     const f32x4 va = acc1[rf][2 * h] + (f32x4){(float)bv[0], (float)bv[1], (float)bv[2], (float)bv[3]};
                     const f32x4 gg = acc1[rf][2 * h + 1] + (f32x4){(float)bg[0], (float)bg[1], (float)bg[2], (float)bg[3]};
+#if FF_ABL & 1
+                    const f32x2 o01 = (f32x2){va[0], va[1]} * (f32x2){gg[0], gg[1]};
+                    const f32x2 o23 = (f32x2){va[2], va[3]} * (f32x2){gg[2], gg[3]};
+#else
                     const f32x2 o01 = ew_vgelu2((f32x2){va[0], va[1]}, (f32x2){gg[0], gg[1]});
                     const f32x2 o23 = ew_vgelu2((f32x2){va[2], va[3]}, (f32x2){gg[2], gg[3]});
+#endif
                     hf[rf][4 * h + 0] = (f16)o01[0];
                     hf[rf][4 * h + 1] = (f16)o01[1];
                     hf[rf][4 * h + 2] = (f16)o23[0];
@@ -223,13 +301,19 @@ __global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
                 for (int u = 0; u < 5; ++u)
 #pragma unroll
                     for (int rf = 0; rf < 2; ++rf)
+#if FF_ABL & 16
+                        asm volatile("" ::"v"(w2f[g4 & 1][u]), "v"(hf_old[rf]));
+#else
                         acc2[rf][g4 * 5 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[g4 & 1][u], hf_old[rf], acc2[rf][g4 * 5 + u], 0, 0, 0);
+#endif
                 FF_PIN();
                 // DMA pieces: 4 per group (W1 pieces 0..9, then W2 pieces 0..4; the last group has 3)
 #pragma unroll
                 for (int k = g4 * 4; k < g4 * 4 + 4 && k < P1 + P2; ++k) {
+#if !(FF_ABL & 2)
                     if (k < P1) glds16(s1 + k * 512, d1 + k * 1024);
                     else glds16(s2 + (k - P1) * 512, d2 + (k - P1) * 1024);
+#endif
                 }
                 FF_PIN();
             }
@@ -267,6 +351,12 @@ __global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
             const int8_t* r2lp = p.r2_lo ? p.r2_lo : (const int8_t*)p.zero_page;
             const int mrb = p.rowbias ? 1 : 0, m1 = p.r1 ? 1 : 0, m2 = p.r2 ? 1 : 0, m1l = p.r1_lo ? 1 : 0, m2l = p.r2_lo ? 1 : 0;
             constexpr int NQ = C / 32;
+#if FF_ABL & 4
+#pragma unroll
+            for (int rf = 0; rf < 2; ++rf)
+#pragma unroll
+                for (int jj = 0; jj < C / 16; ++jj) asm volatile("" ::"v"(acc2[rf][jj]));
+#else
 #pragma unroll
             for (int rf = 0; rf < 2; ++rf) {
                 const int m = m_w0 + rf * 16 + frow;
@@ -312,6 +402,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
                     }
                 }
             }
+#endif
         }
         FF_WAIT_VM0();      // next tile's x fragments (and this tile's stores) are complete before the chunk loop starts
     }
@@ -334,6 +425,8 @@ extern "C" ew_status ew_ff_geglu320_f16(const ew_ff_args* a, void* stream) {
     EW_REQUIRE(!a->rowbias || a->ld_rowbias % 8 == 0, "ew_ff_geglu320_f16: ld_rowbias must be a multiple of 8");
     EW_REQUIRE((!a->r1_lo || a->r1) && (!a->r2_lo || a->r2), "ew_ff_geglu320_f16: r1_lo / r2_lo need r1 / r2");
     EW_REQUIRE((long long)a->M * C * 2 < (1LL << 40), "ew_ff_geglu320_f16: M too large");
+    EW_REQUIRE((a->ln_gamma != nullptr) == (a->ln_beta != nullptr), "ew_ff_geglu320_f16: ln_gamma and ln_beta go together");
+    EW_REQUIRE(a->ln_gamma || (!a->x_lo && !a->addvec), "ew_ff_geglu320_f16: x_lo / addvec need the LayerNorm prologue (ln_gamma)");
     FfP p;
     p.x = (const f16*)a->x; p.w1p = (const f16*)a->w1p; p.b1p = (const f16*)a->b1p; p.w2p = (const f16*)a->w2p; p.b2 = (const f16*)a->b2;
     p.rowbias = (const f16*)a->rowbias; p.r1 = (const f16*)a->r1; p.r2 = (const f16*)a->r2;
@@ -342,20 +435,25 @@ extern "C" ew_status ew_ff_geglu320_f16(const ew_ff_args* a, void* stream) {
     p.M = a->M; p.rows_per_group = a->rows_per_group; p.ld_rowbias = a->rowbias ? a->ld_rowbias : 0;
     p.n_tiles = ew_cdiv(a->M, BM);
     p.c_acc = a->c_acc; p.c_r1 = a->r1 ? a->c_r1 : 0.f; p.c_r2 = a->r2 ? a->c_r2 : 0.f;
+    p.x_lo = (const int8_t*)a->x_lo; p.ln_gamma = (const f16*)a->ln_gamma; p.ln_beta = (const f16*)a->ln_beta;
+    p.addvec = (const f16*)a->addvec; p.add_rpg = a->add_rows_per_group >= 1 ? a->add_rows_per_group : 1; p.ln_eps = a->ln_eps;
     const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
-    const bool lo = a->r1_lo || a->r2_lo || a->out_lo;
+    const bool lo = a->r1_lo || a->r2_lo || a->out_lo || a->x_lo;
     const bool r2 = a->r2 != nullptr;
     hipStream_t s = (hipStream_t)stream;
-#define FF_LAUNCH(LO_, R2_)                                                                                                \
+#define FF_LAUNCH(LO_, R2_, XLO_)                                                                                          \
     do {                                                                                                                   \
         static std::atomic<unsigned long long> mask{0};                                                                    \
-        if (ew_status st = ew_ensure_dynamic_lds((const void*)ff320_kernel<LO_, R2_>, LDS_BYTES, mask)) return st;         \
-        hipLaunchKernelGGL((ff320_kernel<LO_, R2_>), dim3(grid), dim3(64 * NWV), LDS_BYTES, s, p);                         \
+        if (ew_status st = ew_ensure_dynamic_lds((const void*)ff320_kernel<LO_, R2_, XLO_>, LDS_BYTES, mask)) return st;   \
+        hipLaunchKernelGGL((ff320_kernel<LO_, R2_, XLO_>), dim3(grid), dim3(64 * NWV), LDS_BYTES, s, p);                   \
     } while (0)
-    if (lo && r2) FF_LAUNCH(true, true);
-    else if (lo) FF_LAUNCH(true, false);
-    else if (r2) FF_LAUNCH(false, true);
-    else FF_LAUNCH(false, false);
+    const bool xlo = a->x_lo != nullptr;
+    if (lo && r2 && xlo) FF_LAUNCH(true, true, true);
+    else if (lo && r2) FF_LAUNCH(true, true, false);
+    else if (lo && xlo) FF_LAUNCH(true, false, true);
+    else if (lo) FF_LAUNCH(true, false, false);
+    else if (r2) FF_LAUNCH(false, true, false);
+    else FF_LAUNCH(false, false, false);
 #undef FF_LAUNCH
     return ew_check_launch("ew_ff_geglu320_f16");
 }

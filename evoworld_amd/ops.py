@@ -487,12 +487,18 @@ def ff_pack(w1, b1, w2):
     return w1p, b1p, w2p
 
 
-def ff_geglu320(x, pack, b2, out, *, rowbias=None, rows_per_group=1, ld_rowbias=None, r1=None, r2=None, c_acc=1.0, c_r1=1.0, c_r2=1.0):
-    """out = c_acc * (GEGLU(x W1^T + b1) W2^T + b2 + rowbias) + c_r1 * r1 + c_r2 * r2 for 320-channel tokens, one kernel
-    (ew_ff_geglu320_f16): x fp16 [M, 320]; pack = ff_pack(...); r1 / r2 / out tensors or `Res`."""
+def ff_geglu320(x, pack, b2, out, *, rowbias=None, rows_per_group=1, ld_rowbias=None, r1=None, r2=None, c_acc=1.0, c_r1=1.0, c_r2=1.0,
+                ln=None, ln_eps=1e-5, addvec=None, add_rows_per_group=1):
+    """out = c_acc * (GEGLU(n W1^T + b1) W2^T + b2 + rowbias) + c_r1 * r1 + c_r2 * r2 for 320-channel tokens, one kernel
+    (ew_ff_geglu320_f16): pack = ff_pack(...); r1 / r2 / out tensors or `Res`.  n = x (fp16 [M, 320]), or with ln = (gamma, beta):
+    n = LayerNorm(x + addvec[m // add_rows_per_group]) computed in the kernel's prologue from the stream x (tensor or `Res`)."""
     lib = _lib.load()
+    x, x_lo = _hl(x)
     _req(x, torch.float16, "x")
     a = _lib.FfArgs()
+    if ln is not None:
+        a.x_lo, a.ln_gamma, a.ln_beta, a.addvec = _ptr(x_lo), _ptr(ln[0]), _ptr(ln[1]), _ptr(addvec)
+        a.add_rows_per_group, a.ln_eps = add_rows_per_group, ln_eps
     r1h, r1l = _hl(r1)
     r2h, r2l = _hl(r2)
     oh, ol = _hl(out)

@@ -229,6 +229,11 @@ class UNetSpatioTemporalConditionModel:
         # ablation (tests/analysis_fp16_floor.py --per-tensor, tag res_h1) its fp16 rounding was the largest storage term left
         # (0.15e-6 of squared rel-L2 against 0.56e-6 for fp16 MFMA operands alone); EW_SPLIT_H1=0 restores the plain fp16 tensor
         self.split_h1 = self.split_heads and os.environ.get("EW_SPLIT_H1", "1") != "0"
+        # EW_FUSED_FF=1: the level-0 feed-forwards (LayerNorm + GEGLU pair + residual epilogue) as ONE kernel (ew_ff_geglu320_f16).
+        # Off by default: it removes 46 GB of HBM traffic per forward (the 1.18 GB intermediate x 30, 15 LayerNorm passes) but its
+        # one-wave-per-SIMD pipeline does not overlap LDS reads / GEGLU arithmetic with the MFMAs well enough yet and measures
+        # +2 ... +4 ms per forward against LayerNorm + two GEMMs
+        self.fused_ff = os.environ.get("EW_FUSED_FF", "0") == "1"
         self._pos_cache = {}
         for hd, c in zip(cfg["num_attention_heads"], cfg["block_out_channels"]):
             if c // hd != 64:
@@ -411,6 +416,10 @@ class UNetSpatioTemporalConditionModel:
                 if tag == "t":
                     d["t_fi1w"], d["t_fi1b"] = geglu(b + ".ff_in.net.0.proj")
                     d["t_fi2w"], d["t_fi2b"] = h(f32(b + ".ff_in.net.2.weight")), h(f32(b + ".ff_in.net.2.bias"))
+                if c == 320 and 4 * c == sd[b + ".ff.net.2.weight"].shape[1]:
+                    # level 0: the LayerNorm + GEGLU feed-forward pairs run as ONE kernel (ew_ff_geglu320_f16) on LDS-image packs
+                    for nm, ff in ((f"{tag}_ffp", ".ff"),) + (((f"{tag}_fip", ".ff_in"),) if tag == "t" else ()):
+                        d[nm] = ops.ff_pack(f32(b + ff + ".net.0.proj.weight"), f32(b + ff + ".net.0.proj.bias"), f32(b + ff + ".net.2.weight"))
             W[t.p] = d
         W["cv_w"], W["cv_b"] = h(torch.cat(cv_w)), h(torch.cat(cv_b))
         self._cv_total = off
@@ -520,33 +529,45 @@ class UNetSpatioTemporalConditionModel:
         # attn1 out-proj + residual + folded single-token cross attention (per batch row)
         h = ops.linear(ao, d["s_ow"], d["s_ob"], out=self._res(rows, C, dev), rowbias=cv_s, rows_per_group=T * S,
                        ld_rowbias=self._cv_total, r1=h, ld_r1=C)
-        n3 = ops.layernorm(h, d["s_norm3g"], d["s_norm3b"])
-        ffh = ops.linear(n3, d["s_f1w"], d["s_f1b"], act=ACT_GEGLU)
-        h = ops.linear(ffh, d["s_f2w"], d["s_f2b"], out=self._res(rows, C, dev), r1=h, ld_r1=C)
-        del ffh
+        fused = self.fused_ff and "s_ffp" in d      # level 0: LayerNorm + GEGLU up-projection + down-projection + residual in one kernel
+        if fused:
+            h = ops.ff_geglu320(h, d["s_ffp"], d["s_f2b"], self._res(rows, C, dev), r1=h, ln=(d["s_norm3g"], d["s_norm3b"]))
+        else:
+            n3 = ops.layernorm(h, d["s_norm3g"], d["s_norm3b"])
+            ffh = ops.linear(n3, d["s_f1w"], d["s_f1b"], act=ACT_GEGLU)
+            h = ops.linear(ffh, d["s_f2w"], d["s_f2b"], out=self._res(rows, C, dev), r1=h, ld_r1=C)
+            del ffh
         # --- TemporalBasicTransformerBlock on frame-major tokens (regroup = addressing) ---
         # x_temporal stream starts as h + time_pos_embed: the sum is formed inside the LayerNorm (for norm_in) and again in
         # the ff_in epilogue (r1 = h, row-bias = the frame's embedding) -- it is never written to HBM
         pos = self._pos_emb(t, B, T)
-        nin = ops.layernorm(h, d["t_norm_ing"], d["t_norm_inb"], addvec=pos, rows_per_group=S)
-        ffh = ops.linear(nin, d["t_fi1w"], d["t_fi1b"], act=ACT_GEGLU)
         # hm after ff_in and after the temporal attention are the two stream tensors whose fp16 rounding matters least
         # (tests/analysis_fp16_floor.py per-tensor ablation: +0.036e-6 and +0.021e-6 of squared rel-L2 against 0.25e-6 for a
         # resblock output): they are kept as plain fp16, which saves their lo halves' write + two reads
-        hm = ops.linear(ffh, d["t_fi2w"], d["t_fi2b"], out=Res.empty(rows, C, dev, False), r1=h, ld_r1=C, rowbias=pos,
-                        rows_per_group=S, ld_rowbias=C)
-        del ffh
+        if fused:
+            hm = ops.ff_geglu320(h, d["t_fip"], d["t_fi2b"], Res.empty(rows, C, dev, False), r1=h, rowbias=pos, rows_per_group=S,
+                                 ld_rowbias=C, ln=(d["t_norm_ing"], d["t_norm_inb"]), addvec=pos, add_rows_per_group=S)
+        else:
+            nin = ops.layernorm(h, d["t_norm_ing"], d["t_norm_inb"], addvec=pos, rows_per_group=S)
+            ffh = ops.linear(nin, d["t_fi1w"], d["t_fi1b"], act=ACT_GEGLU)
+            hm = ops.linear(ffh, d["t_fi2w"], d["t_fi2b"], out=Res.empty(rows, C, dev, False), r1=h, ld_r1=C, rowbias=pos,
+                            rows_per_group=S, ld_rowbias=C)
+            del ffh
         n1 = ops.layernorm(hm, d["t_norm1g"], d["t_norm1b"])
         qkv = ops.gemm_fp8(*ops.quant_rows_fp8(n1), *d["t_qkv8"]) if self.qkv_fp8 else ops.linear(n1, d["t_qkv"])
         ops.attn_temporal(qkv, qkv[:, C:], qkv[:, 2 * C:], ao, B, T, S, t.heads, 3 * C, C)
         del qkv
         hm = ops.linear(ao, d["t_ow"], d["t_ob"], out=Res.empty(rows, C, dev, False), rowbias=cv_t, rows_per_group=T * S,
                         ld_rowbias=self._cv_total, r1=hm, ld_r1=C)
-        n3 = ops.layernorm(hm, d["t_norm3g"], d["t_norm3b"])
-        ffh = ops.linear(n3, d["t_f1w"], d["t_f1b"], act=ACT_GEGLU)
         a = d["mix"]  # AlphaBlender: a*x_spatial + (1-a)*x_temporal, x_temporal = hm + ff(..); hb is only a GEMM operand
-        hb = ops.linear(ffh, d["t_f2w"], d["t_f2b"], c_acc=1.0 - a, r1=hm, ld_r1=C, c_r1=1.0 - a, r2=h, ld_r2=C, c_r2=a)
-        del ffh
+        if fused:
+            hb = ops.ff_geglu320(hm, d["t_ffp"], d["t_f2b"], torch.empty(rows, C, dtype=torch.float16, device=dev), c_acc=1.0 - a, r1=hm,
+                                 c_r1=1.0 - a, r2=h, c_r2=a, ln=(d["t_norm3g"], d["t_norm3b"]))
+        else:
+            n3 = ops.layernorm(hm, d["t_norm3g"], d["t_norm3b"])
+            ffh = ops.linear(n3, d["t_f1w"], d["t_f1b"], act=ACT_GEGLU)
+            hb = ops.linear(ffh, d["t_f2w"], d["t_f2b"], c_acc=1.0 - a, r1=hm, ld_r1=C, c_r1=1.0 - a, r2=h, ld_r2=C, c_r2=a)
+            del ffh
         return ops.linear(hb, d["pow"], d["pob"], out=self._res(rows, C, dev), r1=x, ld_r1=C)
 
     # ---------------- forward ----------------

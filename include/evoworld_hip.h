@@ -119,7 +119,7 @@ ew_status ew_gemm_streamk_init(void* stream);
  * = diffusers FeedForward(320, activation_fn="geglu") (net.0 GEGLU projection 320 -> 2 x 1280, net.2 Linear 1280 -> 320) of
  * BasicTransformerBlock.ff / TemporalBasicTransformerBlock.ff_in / .ff (instantiated via evoworld/trainer/unet_plucker.py:161-233)
  * with the residual / AlphaBlender epilogue of ew_gemm_f16; the 1280-wide intermediate never goes to HBM.  x: fp16 [M, 320]
- * (the LayerNorm output); w1p / b1p / w2p: the weights in the kernel's LDS-image packs (layout: csrc/ff_fused.hip, built by
+ * (the LayerNorm output, or the stream itself with the LayerNorm prologue below); w1p / b1p / w2p: the weights in the kernel's LDS-image packs (layout: csrc/ff_fused.hip, built by
  * evoworld_amd.ops.ff_pack); b2 fp16 [320]; r1 / r2 / out [M, 320] with optional lo8 companions as in ew_gemm_args. */
 typedef struct ew_ff_args {
     const void* x;
@@ -138,6 +138,16 @@ typedef struct ew_ff_args {
     int M, C, hidden;      /* C = 320, hidden = 1280 */
     int rows_per_group, ld_rowbias;
     float c_acc, c_r1, c_r2;
+    /* Optional LayerNorm prologue (ln_gamma != NULL): x is then the residual stream (hi fp16 + optional lo8 companion x_lo), the
+     * kernel computes LayerNorm(x + addvec[m / add_rows_per_group]) (addvec: fp16 [G, 320] or NULL -- the time_pos_embed of
+     * TemporalBasicTransformerBlock.norm_in) with ln_gamma / ln_beta / ln_eps in registers, exactly as ew_layernorm_f16 does, and
+     * feeds it to the up-projection: the normalised tensor is never written either. */
+    const void* x_lo;
+    const void* ln_gamma;
+    const void* ln_beta;
+    const void* addvec;
+    int add_rows_per_group;
+    float ln_eps;
 } ew_ff_args;
 ew_status ew_ff_geglu320_f16(const ew_ff_args* args, void* stream);
 

@@ -115,3 +115,35 @@ def test_fused_ff_is_deterministic_and_times():
     pair = t(lambda: _two_gemm(x, w1, b1, w2, b2, o2, r1=h, ld_r1=C))
     fl = 2.0 * M * C * 2560 + 2.0 * M * 1280 * C
     print(f"level-0 feed-forward (460800 tokens): fused {fused:.3f} ms ({fl / fused / 1e9:.0f} TF/s) vs two GEMMs {pair:.3f} ms ({fl / pair / 1e9:.0f} TF/s)")
+
+
+@pytest.mark.parametrize("form,M", [("s_ff", 460800), ("t_ffin", 25600 + 50), ("t_ff", 25600)])
+def test_fused_ff_with_layernorm_prologue(form, M):
+    """LayerNorm (+ per-frame add vector) in the kernel's prologue == ew_layernorm_f16 followed by the fused kernel without it."""
+    from evoworld_amd import ops
+    C = 320
+    w1, b1, w2, b2 = _weights(30)
+    pack = ops.ff_pack(w1, b1, w2)
+    gm, bt = (torch.rand(C, generator=_g(7)) + 0.5).half().to(DEV), (torch.rand(C, generator=_g(8)) - 0.5).half().to(DEV)
+    h = ops.Res.from_float((torch.randn(M, C, generator=_g(1)) * 2 + 0.3).to(DEV))
+    hm = (torch.randn(M, C, generator=_g(2)) * 2).half().to(DEV)
+    S = 64
+    pos = torch.randn((M + S - 1) // S, C, generator=_g(3)).half().to(DEV)
+    if form == "s_ff":
+        x, kw, lnkw = h, dict(r1=h), {}
+        mk = lambda: ops.Res.empty(M, C, DEV, True)
+    elif form == "t_ffin":
+        x, kw, lnkw = h, dict(r1=h, rowbias=pos, rows_per_group=S, ld_rowbias=C), dict(addvec=pos, rows_per_group=S)
+        mk = lambda: torch.empty(M, C, dtype=torch.float16, device=DEV)
+    else:
+        a = 0.37
+        x, kw, lnkw = hm, dict(c_acc=1 - a, r1=hm, c_r1=1 - a, r2=h, c_r2=a), {}
+        mk = lambda: torch.empty(M, C, dtype=torch.float16, device=DEV)
+    n = ops.layernorm(x, gm, bt, **lnkw)
+    want, got = mk(), mk()
+    ops.ff_geglu320(n, pack, b2, want, **kw)
+    ops.ff_geglu320(x, pack, b2, got, ln=(gm, bt), ln_eps=1e-5, addvec=lnkw.get("addvec"), add_rows_per_group=lnkw.get("rows_per_group", 1), **kw)
+    a_, b_ = (got.float(), want.float())
+    e = rel_l2(a_.cpu(), b_.cpu())
+    print(f"fused feed-forward with LayerNorm prologue {form} M={M}: rel-L2 vs separate LayerNorm kernel {e:.2e}")
+    assert torch.isfinite(a_).all() and e < 1e-4
