@@ -1,44 +1,54 @@
-// ff_fused.hip -- fused GEGLU feed-forward for the 320-channel (level 0) transformer blocks, gfx950 (round 3).
+// ff_fused.hip -- fused LayerNorm + GEGLU feed-forward for the 320-channel (level 0) transformer blocks, gfx950 (round 3).
 //
-//   out = c_acc * ( GEGLU(x W1^T + b1) W2^T + b2 + rowbias ) + c_r1 * r1 + c_r2 * r2        x: [M, 320] fp16 (LayerNorm output)
+//   out = c_acc * ( GEGLU(n W1^T + b1) W2^T + b2 + rowbias ) + c_r1 * r1 + c_r2 * r2,   n = x  or  LayerNorm(x + addvec)
 //
 // i.e. diffusers FeedForward(dim, activation_fn="geglu") = net.0 (GEGLU proj 320 -> 2 x 1280) + net.2 (Linear 1280 -> 320) of
-// BasicTransformerBlock.ff / TemporalBasicTransformerBlock.ff / .ff_in (instantiated through evoworld/trainer/unet_plucker.py:
-// 161-233), with the residual / AlphaBlender epilogue of ew_gemm_f16.
+// BasicTransformerBlock.ff / TemporalBasicTransformerBlock.ff / .ff_in with the LayerNorm in front of it (norm3 / norm_in;
+// instantiated through evoworld/trainer/unet_plucker.py:161-233) and the residual / AlphaBlender
+// epilogue of ew_gemm_f16.
 //
-// Why a fused kernel: as two GEMMs the 1280-wide GEGLU intermediate of level 0 (460800 x 1280 fp16 = 1.18 GB) is written and
-// read back 15 times per forward; the pair is 11 % of the forward and runs at 860 TF/s.  Here it never leaves the chip:
-//   * one workgroup = 4 waves, ONE wave per SIMD with the whole 512-entry register file (accumulators in the accumulation
-//     half): a wave owns 32 rows of a 128-row tile -- their x fragments (80 registers) stay resident for the whole tile, the
-//     down-projection accumulator 32 x 320 (160 registers) too;
-//   * the hidden dimension is walked in 40 chunks of 32: up-projection of the chunk (value + gate columns: a 32 x 64
-//     accumulator, K = 320, 80 MFMAs) -> bias + value * gelu(gate) in registers -> the result IS the A fragment of the
-//     down-projection's k-step (the host packs W1's rows so that the four outputs a lane owns per fragment pair are consecutive
-//     hidden indices) -> 40 MFMAs into the 32 x 320 accumulator.  No LDS round trip for the intermediate, no second pass over x;
-//   * only the weights go through LDS, one chunk image (W1 40 KB + W2 20 KB) per step, double-buffered, by LDS-DMA from
-//     host-packed images that are byte copies of the LDS layout (every DMA instruction reads 1 KB contiguous; the 16-byte-slot
-//     XOR swizzles that make the ds_read_b128 fragment reads conflict-free are baked into the pack).  One barrier per chunk: a
-//     chunk's image is requested a whole chunk (120 MFMAs per wave) before it is needed.  2.4 MB of weights are shared by all 256
-//     workgroups walking them in step: L2-resident.
+// Why a fused kernel: as LayerNorm + two GEMMs the 1280-wide GEGLU intermediate of level 0 (460800 x 1280 fp16 = 1.18 GB) is
+// written and read back 15 times per forward and the normalised tensor 15 times more.  Here neither leaves the chip:
+//   * one workgroup = 8 waves as 4 (M) x 2 (N), two per SIMD, on a 128-row tile.  A wave owns 32 rows; their (normalised) x
+//     fragments stay in 80 registers for the whole tile.  The LayerNorm runs on those registers (prologue);
+//   * the hidden dimension is walked in 40 chunks of 32.  Up-projection of a chunk: the wave computes the value + gate columns
+//     of ITS half of the chunk (16 hidden units: 2 fragments x 2 row fragments x 10 k-steps = 40 MFMAs), applies bias and
+//     value * gelu(gate) in registers and leaves its four halves per lane in a small LDS exchange buffer; after the chunk's
+//     barrier either wave of the pair reads the complete A fragment (32 hidden units) back with one ds_read_b128 per row fragment
+//     and multiplies it into ITS half of the 320 output columns (10 fragments x 2 = 20 MFMAs, accumulator 32 x 160 = 80
+//     registers).  W1's rows are packed so that the four outputs a lane owns per (value, gate) fragment pair are consecutive
+//     hidden indices -- the GEGLU result is already in A-fragment order;
+//   * the down-projection trails the up-projection by one chunk, so ONE barrier per chunk serves both the weight hand-over
+//     and the GEGLU exchange, and the GEGLU arithmetic / DMA requests of a chunk run in the shadow of MFMAs;
+//   * weights go through LDS one chunk image (W1 40 KB + W2 20 KB) per step, double-buffered, by LDS-DMA from host-packed
+//     images that are byte copies of the LDS layout (1 KB contiguous per DMA instruction; the XOR swizzles that make the
+//     ds_read_b128 fragment reads conflict-free are baked into the pack).  A chunk's image is requested a whole chunk before it is
+//     needed.  The 2.4 MB of weights are shared by all 256 workgroups walking them in step: L2-resident;
 //   * the epilogue is the LDS-free "direct" form of gemm3_f16.hip (W2's rows are staged permuted so that a lane's accumulator
-//     pair is 8 consecutive output columns: 16-byte accesses for bias / row-bias / residual hi / output hi, 8-byte for lo8).
-// Same rounding points as the two-GEMM path (fp32 accumulation, GEGLU in fp32, intermediate rounded to fp16 once, fp32
-// accumulation, output split or fp16): results agree to fp32 summation order.
+//     pair is 8 consecutive output columns); all residual operands of a row fragment are requested before the first is used.
+// Same rounding points as the separate kernels (LayerNorm output rounded to fp16, fp32 accumulation, GEGLU in fp32, intermediate
+// rounded to fp16 once, fp32 accumulation, output split or fp16): results agree to fp32 summation order.
 #include "gemm_common.h"
 #include <type_traits>
 
 namespace {
 
 constexpr int C = 320, HID = 1280, CH = 32, NCH = HID / CH;       // 40 chunks of 32 hidden units
-constexpr int BM = 128, WROWS = 32, NWV = 4;                      // 4 waves x 32 rows
+#ifndef FF_WM
+#define FF_WM 4           /* waves along M: 4 -> 8 waves (2 per SIMD, 256 registers), 32 rows each; 2 -> 4 waves (1 per SIMD, 512 registers), 64 rows each */
+#endif
+constexpr int BM = 128, WAVES_N = 2, NWV = FF_WM * WAVES_N, WROWS = BM / FF_WM, RF = WROWS / 16;
 constexpr int KS = C / 32;                                         // 10 k-steps of the up-projection
 constexpr int KT = C / 64;                                         // W1 chunk image = 5 K-tiles of [64 staged rows][64 k]
 constexpr int W1_KT = 64 * 128;                                    // 8 KB
 constexpr int W1_TILE = KT * W1_KT;                                // 40 KB per chunk
 constexpr int W2_TILE = C * CH * 2;                                // 320 staged rows x 32 k x 2 B = 20 KB per chunk
-constexpr int LDS_W1 = 0, LDS_W2 = 2 * W1_TILE, LDS_B1 = LDS_W2 + 2 * W2_TILE;   // both double-buffered by chunk
-constexpr int LDS_BYTES = LDS_B1 + 2 * HID * 2;                    // 80 + 40 + 5 KB
-constexpr int P1 = W1_TILE / 1024 / NWV, P2 = W2_TILE / 1024 / NWV;   // DMA pieces per wave and chunk: 10 / 5
+constexpr int HX_TILE = (BM / 16) * 64 * 16;                       // GEGLU exchange: 8 row fragments x 64 lanes x 16 B = 8 KB per chunk
+constexpr int LDS_W1 = 0, LDS_W2 = 2 * W1_TILE, LDS_HX = LDS_W2 + 2 * W2_TILE, LDS_B1 = LDS_HX + 2 * HX_TILE;
+constexpr int LDS_BYTES = LDS_B1 + 2 * HID * 2;                    // 80 + 40 + 16 + 5 KB
+constexpr int P1 = W1_TILE / 1024 / NWV;                           // W1 DMA pieces per wave and chunk (5); W2's 20 pieces are dealt round-robin
+constexpr int P2MAX = (W2_TILE / 1024 + NWV - 1) / NWV;            // 3 (waves 4-7 issue 2)
+constexpr int NJ2 = C / 16 / WAVES_N;                              // 10 output fragments per wave
 
 struct FfP {
     const f16* x;
@@ -67,39 +77,37 @@ struct FfP {
 // queue is empty.  With an opaque asm wait it kept a vmcnt(0) in front of the first use of the x fragments in EVERY chunk (their
 // loads are issued at the end of the previous tile), which drained the weight DMA right after it was requested: 3.4x slower.
 #define FF_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
+#define FF_PIN() __builtin_amdgcn_sched_barrier(0)
+#ifndef FF_ABL
+#define FF_ABL 0          /* ablation builds (tools/experiments): 1 no GEGLU math, 2 no DMA, 4 no epilogue, 8 no up-proj MFMA, 16 no down-proj MFMA */
+#endif
 
 template <bool LO, bool R2, bool XLO>
-__global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
+__global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
     const int frow = lane & 15, fks = lane >> 4, sw = frow & 7;
 
-    // W2 buffers start as zeros: the first chunk of a tile runs the trailing down-projection slot on a zero A fragment (no
-    // branch in the pipeline), which must not meet NaN bit patterns of uninitialised LDS (later tiles find old weights there)
-    for (int i = tid; i < 2 * W2_TILE / 16; i += 64 * NWV) *(f16x8*)(smem + LDS_W2 + i * 16) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    // W2 and exchange buffers start as zeros: the first chunk of a tile runs the trailing down-projection slot on a zero A
+    // fragment (no branch in the pipeline), which must not meet NaN bit patterns of uninitialised LDS
+    for (int i = tid; i < (2 * W2_TILE + 2 * HX_TILE) / 16; i += 64 * NWV) *(f16x8*)(smem + LDS_W2 + i * 16) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
     // packed b1 -> LDS once (5 KB)
     for (int i = tid; i < 2 * HID * 2 / 16; i += 64 * NWV) *(f16x8*)(smem + LDS_B1 + i * 16) = *(const f16x8*)((const char*)p.b1p + i * 16);
 
     const int G = gridDim.x;
     const int n_my = (p.n_tiles - (int)blockIdx.x + G - 1) / G;            // tiles blockIdx.x, +G, ...
     if (n_my <= 0) return;
-
     const int CC_total = n_my * NCH;
+
     // ---- weight DMA stream: global chunk cc <-> W1 / W2 chunk images (cc mod 40), identical for every tile; buffers cc & 1
-    // prologue: chunk 0 and chunk 1 (W1: ring of 2 by chunk; W2: ring of 2, one chunk behind -- see the hand-over below)
     auto issue_w1 = [&](int c_mod, int slot) __attribute__((always_inline)) {
         const f16* s1 = (const f16*)((const char*)p.w1p + (size_t)c_mod * W1_TILE + wave * (P1 * 1024)) + lane * 8;
         char* d1 = smem + LDS_W1 + slot * W1_TILE + wave * (P1 * 1024);
 #pragma unroll
         for (int k = 0; k < P1; ++k) glds16(s1 + k * 512, d1 + k * 1024);
-    };
-    auto issue_w2 = [&](int c_mod, int slot) __attribute__((always_inline)) {
-        const f16* s2 = (const f16*)((const char*)p.w2p + (size_t)c_mod * W2_TILE + wave * (P2 * 1024)) + lane * 8;
-        char* d2 = smem + LDS_W2 + slot * W2_TILE + wave * (P2 * 1024);
-#pragma unroll
-        for (int k = 0; k < P2; ++k) glds16(s2 + k * 512, d2 + k * 1024);
     };
     issue_w1(0, 0);
     int cc = 0;                                 // global chunk index
@@ -112,33 +120,30 @@ __global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
     // ds_read_b128 services together are (fks, rows 0-3 | 12-15) + (fks+1, rows 4-11) -- g makes their 16 slots distinct
     int rd1[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) rd1[h] = frow * 128 + (((h * 4 + fks) ^ sw) << 4);
+    for (int h = 0; h < 2; ++h) rd1[h] = (2 * wn * 16 + frow) * 128 + (((h * 4 + fks) ^ sw) << 4);      // this wave's fragments j = 2 wn, 2 wn + 1
     const int gq = (0x78 >> (2 * ((frow >> 2) & 3))) & 3;             // {0, 2, 3, 1}[(frow >> 2) & 3]
-    const int rd2 = frow * 64 + ((fks ^ gq) << 4);
+    const int rd2 = (wn * NJ2 * 16 + frow) * 64 + ((fks ^ gq) << 4);                                    // this wave's fragments jj = 10 wn ...
+    // exchange buffer: row fragment (wm, rf), lane L: 16 bytes = the A fragment of the chunk's k-step; this wave writes bytes 8 wn ..
+    const int hx_off = (wm * RF * 64 + lane) * 16;
 #define FF_W1F(buf, ks_, j_) (*(const f16x8*)((buf) + ((ks_) >> 1) * W1_KT + (j_) * 2048 + rd1[(ks_) & 1]))
-#define FF_PIN() __builtin_amdgcn_sched_barrier(0)
-#ifndef FF_ABL
-#define FF_ABL 0          /* ablation builds (tools/experiments): 1 no GEGLU math, 2 no DMA, 4 no epilogue, 8 no up-proj MFMA, 16 no down-proj MFMA */
-#endif
 
     // W1 fragment ring: k-step ks uses wf[ks % 3]; the fragments of ks+2 are read while ks is multiplied; the first two sets of
     // a chunk are read during the second phase of the PREVIOUS chunk.
-    f16x8 wf[3][4];
+    f16x8 wf[3][2];
     {
         const char* w1b = smem + LDS_W1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { wf[0][j] = FF_W1F(w1b, 0, j); wf[1][j] = FF_W1F(w1b, 1, j); }
+        for (int j = 0; j < 2; ++j) { wf[0][j] = FF_W1F(w1b, 0, j); wf[1][j] = FF_W1F(w1b, 1, j); }
     }
 
-    // ---- x fragments of this wave's 32 rows of a tile: row frow (+16 rf), k = ks*32 + fks*8 .. +8.  The NEXT tile's fragments
-    // are requested before the epilogue of the current one (the registers are free once the last up-projection is done), so
-    // their HBM latency is covered by the epilogue.
-    f16x8 xf[2][KS];
-    u32x2 xl[2][XLO ? KS : 1];                 // lo8 companions of the LayerNorm input stream
+    // ---- x fragments of this wave's 32 rows of a tile: row frow (+16 rf), k = ks*32 + fks*8 .. +8 (both waves of an M pair hold
+    // the same rows).  The NEXT tile's fragments are requested before the epilogue of the current one.
+    f16x8 xf[RF][KS];
+    u32x2 xl[RF][XLO ? KS : 1];                 // lo8 companions of the LayerNorm input stream
     auto load_x = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
-        for (int rf = 0; rf < 2; ++rf) {
-            const int m = min(tile * BM + wave * WROWS + rf * 16 + frow, p.M - 1);
+        for (int rf = 0; rf < RF; ++rf) {
+            const int m = min(tile * BM + wm * WROWS + rf * 16 + frow, p.M - 1);
             const f16* xp = p.x + (size_t)m * C + fks * 8;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) xf[rf][ks] = *(const f16x8*)(xp + ks * 32);
@@ -155,8 +160,8 @@ __global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
     // (frow, fks = 0..3) x 10 fragments x 8: the values are re-decoded in each pass instead of being kept in fp32.
     auto ln_x = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
-        for (int rf = 0; rf < 2; ++rf) {
-            const int m = min(tile * BM + wave * WROWS + rf * 16 + frow, p.M - 1);
+        for (int rf = 0; rf < RF; ++rf) {
+            const int m = min(tile * BM + wm * WROWS + rf * 16 + frow, p.M - 1);
             const f16* ap = p.addvec ? p.addvec + (size_t)(m / p.add_rpg) * C + fks * 8 : p.zero_page;
             const int ma = p.addvec ? 1 : 0;
             auto val = [&](int ks, float (&v)[8]) __attribute__((always_inline)) {
@@ -208,42 +213,42 @@ __global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
 
     for (int ti = 0; ti < n_my; ++ti) {
         const int tile = (int)blockIdx.x + ti * G;
-        const int m_w0 = tile * BM + wave * WROWS;
+        const int m_w0 = tile * BM + wm * WROWS;
         if (p.ln_gamma) ln_x(tile);
-        f32x4 acc2[2][C / 16];
+        f32x4 acc2[RF][NJ2];
 #pragma unroll
-        for (int rf = 0; rf < 2; ++rf)
+        for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
-            for (int jj = 0; jj < C / 16; ++jj) acc2[rf][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        f16x8 hf_old[2] = {};                   // GEGLU output of the previous chunk (A fragment of its down-projection k-step)
+            for (int jj = 0; jj < NJ2; ++jj) acc2[rf][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f16x8 hf_old[RF] = {};                  // complete GEGLU A fragments of the previous chunk (zero before the tile's first)
 
         // Software pipeline over the chunks of the tile.  Iteration c:
-        //   phase 1: up-projection of chunk c (80 MFMAs; W1 fragments two k-steps ahead)
-        //   hand-over barrier: W1 buffer cc & 1 and W2 buffer cc & 1 (down-projection of chunk c-2 is done) are free; this
-        //            wave's pieces of W1(cc+1) and W2(cc-1), requested a chunk ago, have landed
-        //   phase 2: GEGLU of chunk c (VALU) interleaved with the down-projection of chunk c-1 (40 MFMAs) and with the DMA
-        //            requests for W1(cc+2) / W2(cc): the VALU slices and the DMA issue run while the MFMA pipe drains
-        // The down-projection therefore trails by one chunk; it is flushed after the last chunk of the tile.
+        //   phase 1: up-projection of chunk c, this wave's half (40 MFMAs; W1 fragments two k-steps ahead)
+        //   barrier: W1 buffer cc & 1 and W2 / exchange buffers cc & 1 are free (down-projection of chunk c-2 is done); this wave's
+        //            pieces of W1(cc+1) and W2(cc-1), requested a chunk ago, have landed; the exchange halves of chunk c-1 are complete
+        //   phase 2: read the A fragments of chunk c-1 from the exchange buffer; GEGLU of chunk c (VALU) -> exchange buffer cc & 1;
+        //            down-projection of chunk c-1 (20 MFMAs); DMA requests for W1(cc+2) / W2(cc)
+        // The down-projection trails by one chunk; it is flushed after the last chunk of the tile.
         for (int c = 0; c < NCH; ++c, ++cc) {
             const char* w1b = smem + LDS_W1 + (cc & 1) * W1_TILE;
             const char* w1n = smem + LDS_W1 + ((cc + 1) & 1) * W1_TILE;
             const char* w2b = smem + LDS_W2 + ((cc + 1) & 1) * W2_TILE;       // W2(cc - 1)
-            f32x4 acc1[2][4];
+            f32x4 acc1[RF][2];
 #pragma unroll
-            for (int rf = 0; rf < 2; ++rf)
+            for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc1[rf][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 2; ++j) acc1[rf][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks + 2 < KS) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) wf[(ks + 2) % 3][j] = FF_W1F(w1b, ks + 2, j);
+                    for (int j = 0; j < 2; ++j) wf[(ks + 2) % 3][j] = FF_W1F(w1b, ks + 2, j);
                 }
                 FF_PIN();
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int rf = 0; rf < 2; ++rf)
+                    for (int rf = 0; rf < RF; ++rf)
 #if FF_ABL & 8
                         asm volatile("" ::"v"(wf[ks % 3][j]), "v"(xf[rf][ks]));
 #else
@@ -255,31 +260,29 @@ __global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
             FF_FENCE();
             __builtin_amdgcn_s_barrier();
             FF_FENCE();
-            // ---- phase 2
-            // (no branches in this phase: on the first chunk of a tile hf_old is zero, and past the end of the block's work the W1
-            // request / fragment reads touch buffers nobody reads again)
-            f16x8 w2f[2][5];
+            // ---- phase 2 (no branches: on the first chunk of a tile the exchange buffer holds zeros -- see the flush -- and past the
+            // end of the block's work the W1 request / fragment reads touch buffers nobody reads again)
+            if (c > 0) {
 #pragma unroll
-            for (int u = 0; u < 5; ++u) w2f[0][u] = *(const f16x8*)(w2b + u * 1024 + rd2);
+                for (int rf = 0; rf < RF; ++rf) hf_old[rf] = *(const f16x8*)(smem + LDS_HX + ((cc + 1) & 1) * HX_TILE + hx_off + rf * 1024);
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { wf[0][j] = FF_W1F(w1n, 0, j); wf[1][j] = FF_W1F(w1n, 1, j); }
-            // DMA requests of this hand-over: W1(cc+2) -> buffer cc & 1 (10 pieces per wave), W2(cc) -> buffer cc & 1 (5 pieces)
+            for (int j = 0; j < 2; ++j) { wf[0][j] = FF_W1F(w1n, 0, j); wf[1][j] = FF_W1F(w1n, 1, j); }
+            // DMA requests of this hand-over: W1(cc+2) -> buffer cc & 1 (5 pieces per wave), W2(cc) -> buffer cc & 1 (pieces wave + 8k)
             int c2 = c + 2;
             c2 = c2 >= NCH ? c2 - NCH : c2;
             const f16* s1 = (const f16*)((const char*)p.w1p + (size_t)c2 * W1_TILE + wave * (P1 * 1024)) + lane * 8;
             char* d1 = smem + LDS_W1 + (cc & 1) * W1_TILE + wave * (P1 * 1024);
-            const f16* s2 = (const f16*)((const char*)p.w2p + (size_t)c * W2_TILE + wave * (P2 * 1024)) + lane * 8;
-            char* d2 = smem + LDS_W2 + (cc & 1) * W2_TILE + wave * (P2 * 1024);
-            f16x8 hf[2];
-            const char* bb = smem + LDS_B1 + (c * 64 + fks * 4) * 2;
+            const f16* s2 = (const f16*)((const char*)p.w2p + (size_t)c * W2_TILE + wave * 1024) + lane * 8;
+            char* d2 = smem + LDS_W2 + (cc & 1) * W2_TILE + wave * 1024;
+            // ---- bias + GEGLU of this wave's half: fragments (value 2 wn, gate 2 wn + 1) -> hidden 8 fks + 4 wn + e of the chunk
+            {
+                const char* bb = smem + LDS_B1 + (c * 64 + 2 * wn * 16 + fks * 4) * 2;
+                const f16x4 bv = *(const f16x4*)bb, bg = *(const f16x4*)(bb + 32);
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                // GEGLU slice g4 = (h, rf): fragment pair (value 2h, gate 2h+1) -> hidden 8 fks + 4h + e of the chunk
-                {
-                    const int h = g4 >> 1, rf = g4 & 1;
-                    const f16x4 bv = *(const f16x4*)(bb + (2 * h) * 32), bg = *(const f16x4*)(bb + (2 * h + 1) * 32);
-                    const f32x4 va = acc1[rf][2 * h] + (f32x4){(float)bv[0], (float)bv[1], (float)bv[2], (float)bv[3]};
-                    const f32x4 gg = acc1[rf][2 * h + 1] + (f32x4){(float)bg[0], (float)bg[1], (float)bg[2], (float)bg[3]};
+                for (int rf = 0; rf < RF; ++rf) {
+                    const f32x4 va = acc1[rf][0] + (f32x4){(float)bv[0], (float)bv[1], (float)bv[2], (float)bv[3]};
+                    const f32x4 gg = acc1[rf][1] + (f32x4){(float)bg[0], (float)bg[1], (float)bg[2], (float)bg[3]};
 #if FF_ABL & 1
                     const f32x2 o01 = (f32x2){va[0], va[1]} * (f32x2){gg[0], gg[1]};
                     const f32x2 o23 = (f32x2){va[2], va[3]} * (f32x2){gg[2], gg[3]};
@@ -287,40 +290,42 @@ __global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
                     const f32x2 o01 = ew_vgelu2((f32x2){va[0], va[1]}, (f32x2){gg[0], gg[1]});
                     const f32x2 o23 = ew_vgelu2((f32x2){va[2], va[3]}, (f32x2){gg[2], gg[3]});
 #endif
-                    hf[rf][4 * h + 0] = (f16)o01[0];
-                    hf[rf][4 * h + 1] = (f16)o01[1];
-                    hf[rf][4 * h + 2] = (f16)o23[0];
-                    hf[rf][4 * h + 3] = (f16)o23[1];
+                    const f16x4 o4 = {(f16)o01[0], (f16)o01[1], (f16)o23[0], (f16)o23[1]};
+                    *(f16x4*)(smem + LDS_HX + (cc & 1) * HX_TILE + hx_off + rf * 1024 + wn * 8) = o4;
                 }
-                if (g4 + 1 < 4) {
+            }
+            FF_PIN();
+            // ---- down-projection of chunk c-1: one k-step x this wave's 10 output fragments x 2 row fragments
 #pragma unroll
-                    for (int u = 0; u < 5; ++u) w2f[(g4 + 1) & 1][u] = *(const f16x8*)(w2b + ((g4 + 1) * 5 + u) * 1024 + rd2);
-                }
+            for (int g2 = 0; g2 < 2; ++g2) {
+                f16x8 w2f[5];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) w2f[u] = *(const f16x8*)(w2b + (g2 * 5 + u) * 1024 + rd2);
                 FF_PIN();
 #pragma unroll
                 for (int u = 0; u < 5; ++u)
 #pragma unroll
-                    for (int rf = 0; rf < 2; ++rf)
+                    for (int rf = 0; rf < RF; ++rf)
 #if FF_ABL & 16
-                        asm volatile("" ::"v"(w2f[g4 & 1][u]), "v"(hf_old[rf]));
+                        asm volatile("" ::"v"(w2f[u]), "v"(hf_old[rf]));
 #else
-                        acc2[rf][g4 * 5 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[g4 & 1][u], hf_old[rf], acc2[rf][g4 * 5 + u], 0, 0, 0);
+                        acc2[rf][g2 * 5 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[u], hf_old[rf], acc2[rf][g2 * 5 + u], 0, 0, 0);
 #endif
                 FF_PIN();
-                // DMA pieces: 4 per group (W1 pieces 0..9, then W2 pieces 0..4; the last group has 3)
+                // DMA pieces of this wave, half per group
+                constexpr int PER = (P1 + P2MAX + 1) / 2;
 #pragma unroll
-                for (int k = g4 * 4; k < g4 * 4 + 4 && k < P1 + P2; ++k) {
+                for (int k = g2 * PER; k < g2 * PER + PER && k < P1 + P2MAX; ++k) {
 #if !(FF_ABL & 2)
                     if (k < P1) glds16(s1 + k * 512, d1 + k * 1024);
-                    else glds16(s2 + (k - P1) * 512, d2 + (k - P1) * 1024);
+                    else if (wave + NWV * (k - P1) < W2_TILE / 1024) glds16(s2 + (k - P1) * NWV * 512, d2 + (k - P1) * NWV * 1024);
 #endif
                 }
                 FF_PIN();
             }
-            hf_old[0] = hf[0];
-            hf_old[1] = hf[1];
         }
-        // ---- flush: down-projection of the tile's last chunk (its W2 image was requested in the last phase 2)
+        // ---- flush: down-projection of the tile's last chunk (its W2 image was requested in the last phase 2, its exchange halves
+        // were written there); the exchange buffer the NEXT tile's first chunk will read as "chunk -1" is zeroed
         {
             FF_WAIT_VM0();
             FF_FENCE();
@@ -328,21 +333,21 @@ __global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
             FF_FENCE();
             const char* w2b = smem + LDS_W2 + ((cc + 1) & 1) * W2_TILE;       // W2(cc - 1): cc already points past the tile
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
+            for (int rf = 0; rf < RF; ++rf) hf_old[rf] = *(const f16x8*)(smem + LDS_HX + ((cc + 1) & 1) * HX_TILE + hx_off + rf * 1024);
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
                 f16x8 w2f[5];
 #pragma unroll
-                for (int u = 0; u < 5; ++u) w2f[u] = *(const f16x8*)(w2b + (g4 * 5 + u) * 1024 + rd2);
+                for (int u = 0; u < 5; ++u) w2f[u] = *(const f16x8*)(w2b + (g2 * 5 + u) * 1024 + rd2);
 #pragma unroll
                 for (int u = 0; u < 5; ++u)
 #pragma unroll
-                    for (int rf = 0; rf < 2; ++rf)
-                        acc2[rf][g4 * 5 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[u], hf_old[rf], acc2[rf][g4 * 5 + u], 0, 0, 0);
+                    for (int rf = 0; rf < RF; ++rf)
+                        acc2[rf][g2 * 5 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[u], hf_old[rf], acc2[rf][g2 * 5 + u], 0, 0, 0);
             }
         }
-        if (ti + 1 < n_my) load_x(tile + G);
-        // ---- epilogue: lane (frow, fks) owns, for pair q, the 8 output columns q*32 + fks*8 .. +8 of rows frow, frow + 16.  With
-        // one wave per SIMD nothing else hides memory latency, so ALL residual operands of a row fragment (10 steps: 60 / 120
-        // registers) are requested before the first one is used: two round trips to HBM per tile instead of twenty.
+        // ---- epilogue: lane (frow, fks) owns, for pair q of this wave's column half, the 8 output columns q*32 + fks*8 .. +8 of rows
+        // frow, frow + 16.  All residual operands of a row fragment are requested before the first one is used.
         {
             const f16* rbp = p.rowbias ? p.rowbias : p.zero_page;
             const f16* r1p = p.r1 ? p.r1 : p.zero_page;
@@ -350,23 +355,27 @@ __global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
             const int8_t* r1lp = p.r1_lo ? p.r1_lo : (const int8_t*)p.zero_page;
             const int8_t* r2lp = p.r2_lo ? p.r2_lo : (const int8_t*)p.zero_page;
             const int mrb = p.rowbias ? 1 : 0, m1 = p.r1 ? 1 : 0, m2 = p.r2 ? 1 : 0, m1l = p.r1_lo ? 1 : 0, m2l = p.r2_lo ? 1 : 0;
-            constexpr int NQ = C / 32;
+            constexpr int NQ = NJ2 / 2;
+            const int n_w0 = wn * (C / WAVES_N) + fks * 8;
 #if FF_ABL & 4
 #pragma unroll
-            for (int rf = 0; rf < 2; ++rf)
+            for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
-                for (int jj = 0; jj < C / 16; ++jj) asm volatile("" ::"v"(acc2[rf][jj]));
+                for (int jj = 0; jj < NJ2; ++jj) asm volatile("" ::"v"(acc2[rf][jj]));
 #else
 #pragma unroll
-            for (int rf = 0; rf < 2; ++rf) {
+            for (int rf = 0; rf < RF; ++rf) {
                 const int m = m_w0 + rf * 16 + frow;
                 const int mc = min(m, p.M - 1);
                 const int g = mc / p.rows_per_group;
                 f16x8 q1v[NQ], q2v[NQ];
+                // the next tile's x fragments are requested once half of the accumulator is dead (register budget), behind the
+                // last row fragment's residual loads (vmcnt is in order: those are waited for with the x loads still in flight)
+                auto next_x = [&]() __attribute__((always_inline)) { if (rf == RF - 1 && ti + 1 < n_my) load_x(tile + G); };
                 u32x2 q1l[NQ], q2l[NQ];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const int n = q * 32 + fks * 8;
+                    const int n = n_w0 + q * 32;
                     q1v[q] = *(const f16x8*)(r1p + ((size_t)mc * C + n) * m1);
                     if (LO) q1l[q] = *(const u32x2*)(r1lp + ((size_t)mc * C + n) * m1l);
                     if (R2) {
@@ -374,9 +383,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void ff320_kernel(const FfP p) {
                         if (LO) q2l[q] = *(const u32x2*)(r2lp + ((size_t)mc * C + n) * m2l);
                     }
                 }
+                next_x();
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const int n = q * 32 + fks * 8;
+                    const int n = n_w0 + q * 32;
                     const f16x8 bvv = *(const f16x8*)(p.b2 + n);
                     const f16x8 rbv = *(const f16x8*)(rbp + (size_t)(g * p.ld_rowbias + n) * mrb);
                     const f32x4 a0 = acc2[rf][2 * q], a1 = acc2[rf][2 * q + 1];

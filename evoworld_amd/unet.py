@@ -229,11 +229,11 @@ class UNetSpatioTemporalConditionModel:
         # ablation (tests/analysis_fp16_floor.py --per-tensor, tag res_h1) its fp16 rounding was the largest storage term left
         # (0.15e-6 of squared rel-L2 against 0.56e-6 for fp16 MFMA operands alone); EW_SPLIT_H1=0 restores the plain fp16 tensor
         self.split_h1 = self.split_heads and os.environ.get("EW_SPLIT_H1", "1") != "0"
-        # EW_FUSED_FF=1: the level-0 feed-forwards (LayerNorm + GEGLU pair + residual epilogue) as ONE kernel (ew_ff_geglu320_f16).
-        # Off by default: it removes 46 GB of HBM traffic per forward (the 1.18 GB intermediate x 30, 15 LayerNorm passes) but its
-        # one-wave-per-SIMD pipeline does not overlap LDS reads / GEGLU arithmetic with the MFMAs well enough yet and measures
-        # +2 ... +4 ms per forward against LayerNorm + two GEMMs
-        self.fused_ff = os.environ.get("EW_FUSED_FF", "0") == "1"
+        # EW_FUSED_FF: the level-0 feed-forwards (GEGLU pair + residual epilogue) through ONE kernel, ew_ff_geglu320_f16: 0 = LayerNorm
+        # + two GEMMs (default), 1 = LayerNorm kernel + fused kernel, 2 = LayerNorm in the fused kernel's prologue.  Off by default:
+        # mode 1 removes 35 GB of HBM traffic per forward (the 1.18 GB intermediate x 30) and is 0.14 ms faster per call in isolation
+        # (1.48 vs 1.62 ms) but measures +0.9 ms per forward in place; mode 2 is +9 ms (profiles/r03_e_*)
+        self.fused_ff = int(os.environ.get("EW_FUSED_FF", "0"))
         self._pos_cache = {}
         for hd, c in zip(cfg["num_attention_heads"], cfg["block_out_channels"]):
             if c // hd != 64:
@@ -529,9 +529,12 @@ class UNetSpatioTemporalConditionModel:
         # attn1 out-proj + residual + folded single-token cross attention (per batch row)
         h = ops.linear(ao, d["s_ow"], d["s_ob"], out=self._res(rows, C, dev), rowbias=cv_s, rows_per_group=T * S,
                        ld_rowbias=self._cv_total, r1=h, ld_r1=C)
-        fused = self.fused_ff and "s_ffp" in d      # level 0: LayerNorm + GEGLU up-projection + down-projection + residual in one kernel
-        if fused:
+        fused = self.fused_ff if "s_ffp" in d else 0     # level 0: LayerNorm + GEGLU up-projection + down-projection + residual in one kernel
+        if fused == 2:
             h = ops.ff_geglu320(h, d["s_ffp"], d["s_f2b"], self._res(rows, C, dev), r1=h, ln=(d["s_norm3g"], d["s_norm3b"]))
+        elif fused:
+            n3 = ops.layernorm(h, d["s_norm3g"], d["s_norm3b"])
+            h = ops.ff_geglu320(n3, d["s_ffp"], d["s_f2b"], self._res(rows, C, dev), r1=h)
         else:
             n3 = ops.layernorm(h, d["s_norm3g"], d["s_norm3b"])
             ffh = ops.linear(n3, d["s_f1w"], d["s_f1b"], act=ACT_GEGLU)
@@ -544,9 +547,12 @@ class UNetSpatioTemporalConditionModel:
         # hm after ff_in and after the temporal attention are the two stream tensors whose fp16 rounding matters least
         # (tests/analysis_fp16_floor.py per-tensor ablation: +0.036e-6 and +0.021e-6 of squared rel-L2 against 0.25e-6 for a
         # resblock output): they are kept as plain fp16, which saves their lo halves' write + two reads
-        if fused:
+        if fused == 2:
             hm = ops.ff_geglu320(h, d["t_fip"], d["t_fi2b"], Res.empty(rows, C, dev, False), r1=h, rowbias=pos, rows_per_group=S,
                                  ld_rowbias=C, ln=(d["t_norm_ing"], d["t_norm_inb"]), addvec=pos, add_rows_per_group=S)
+        elif fused:
+            nin = ops.layernorm(h, d["t_norm_ing"], d["t_norm_inb"], addvec=pos, rows_per_group=S)
+            hm = ops.ff_geglu320(nin, d["t_fip"], d["t_fi2b"], Res.empty(rows, C, dev, False), r1=h, rowbias=pos, rows_per_group=S, ld_rowbias=C)
         else:
             nin = ops.layernorm(h, d["t_norm_ing"], d["t_norm_inb"], addvec=pos, rows_per_group=S)
             ffh = ops.linear(nin, d["t_fi1w"], d["t_fi1b"], act=ACT_GEGLU)
@@ -560,9 +566,13 @@ class UNetSpatioTemporalConditionModel:
         hm = ops.linear(ao, d["t_ow"], d["t_ob"], out=Res.empty(rows, C, dev, False), rowbias=cv_t, rows_per_group=T * S,
                         ld_rowbias=self._cv_total, r1=hm, ld_r1=C)
         a = d["mix"]  # AlphaBlender: a*x_spatial + (1-a)*x_temporal, x_temporal = hm + ff(..); hb is only a GEMM operand
-        if fused:
+        if fused == 2:
             hb = ops.ff_geglu320(hm, d["t_ffp"], d["t_f2b"], torch.empty(rows, C, dtype=torch.float16, device=dev), c_acc=1.0 - a, r1=hm,
                                  c_r1=1.0 - a, r2=h, c_r2=a, ln=(d["t_norm3g"], d["t_norm3b"]))
+        elif fused:
+            n3 = ops.layernorm(hm, d["t_norm3g"], d["t_norm3b"])
+            hb = ops.ff_geglu320(n3, d["t_ffp"], d["t_f2b"], torch.empty(rows, C, dtype=torch.float16, device=dev), c_acc=1.0 - a, r1=hm,
+                                 c_r1=1.0 - a, r2=h, c_r2=a)
         else:
             n3 = ops.layernorm(hm, d["t_norm3g"], d["t_norm3b"])
             ffh = ops.linear(n3, d["t_f1w"], d["t_f1b"], act=ACT_GEGLU)
