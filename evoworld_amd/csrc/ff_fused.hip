@@ -29,6 +29,7 @@
 // Same rounding points as the separate kernels (LayerNorm output rounded to fp16, fp32 accumulation, GEGLU in fp32, intermediate
 // rounded to fp16 once, fp32 accumulation, output split or fp16): results agree to fp32 summation order.
 #include "gemm_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -68,7 +69,7 @@ struct FfP {
     const f16* ln_gamma;
     const f16* ln_beta;
     const f16* addvec;
-    int M, rows_per_group, ld_rowbias, n_tiles, add_rpg;
+    int M, rows_per_group, ld_rowbias, n_tiles, add_rpg, stagger;
     float c_acc, c_r1, c_r2, ln_eps;
 };
 
@@ -101,6 +102,17 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
     const int n_my = (p.n_tiles - (int)blockIdx.x + G - 1) / G;            // tiles blockIdx.x, +G, ...
     if (n_my <= 0) return;
     const int CC_total = n_my * NCH;
+#ifndef FF_STAGGER
+#define FF_STAGGER 16
+#endif
+    // Start stagger.  All tiles cost the same, so 256 workgroups started together stay in step for the whole launch: every CU asks
+    // L2 for the same 60 KB weight chunk at the same moment and every CU's epilogue (the only HBM traffic) falls into the same few
+    // microseconds.  n_tiles is rarely a multiple of the grid: workgroups that own one tile fewer than the busiest have a whole tile
+    // time of slack, and spend part of it up front -- (blockIdx mod 16) x ~4 us (s_sleep 127 = 8128 clocks)
+    if (FF_STAGGER > 0 && n_my < (p.n_tiles + G - 1) / G) {
+        const int d = (int)(blockIdx.x % FF_STAGGER) * p.stagger;
+        for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     // ---- weight DMA stream: global chunk cc <-> W1 / W2 chunk images (cc mod 40), identical for every tile; buffers cc & 1
     auto issue_w1 = [&](int c_mod, int slot) __attribute__((always_inline)) {
@@ -448,6 +460,8 @@ extern "C" ew_status ew_ff_geglu320_f16(const ew_ff_args* a, void* stream) {
     p.x_lo = (const int8_t*)a->x_lo; p.ln_gamma = (const f16*)a->ln_gamma; p.ln_beta = (const f16*)a->ln_beta;
     p.addvec = (const f16*)a->addvec; p.add_rpg = a->add_rows_per_group >= 1 ? a->add_rows_per_group : 1; p.ln_eps = a->ln_eps;
     const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
+    static const int stagger_env = [] { const char* e = getenv("EW_FF_STAGGER"); return e ? atoi(e) : 1; }();
+    p.stagger = stagger_env;
     const bool lo = a->r1_lo || a->r2_lo || a->out_lo || a->x_lo;
     const bool r2 = a->r2 != nullptr;
     hipStream_t s = (hipStream_t)stream;

@@ -230,10 +230,10 @@ class UNetSpatioTemporalConditionModel:
         # (0.15e-6 of squared rel-L2 against 0.56e-6 for fp16 MFMA operands alone); EW_SPLIT_H1=0 restores the plain fp16 tensor
         self.split_h1 = self.split_heads and os.environ.get("EW_SPLIT_H1", "1") != "0"
         # EW_FUSED_FF: the level-0 feed-forwards (GEGLU pair + residual epilogue) through ONE kernel, ew_ff_geglu320_f16: 0 = LayerNorm
-        # + two GEMMs (default), 1 = LayerNorm kernel + fused kernel, 2 = LayerNorm in the fused kernel's prologue.  Off by default:
-        # mode 1 removes 35 GB of HBM traffic per forward (the 1.18 GB intermediate x 30) and is 0.14 ms faster per call in isolation
-        # (1.48 vs 1.62 ms) but measures +0.9 ms per forward in place; mode 2 is +9 ms (profiles/r03_e_*)
-        self.fused_ff = int(os.environ.get("EW_FUSED_FF", "0"))
+        # + two GEMMs, 1 = LayerNorm kernel + fused kernel (default), 2 = LayerNorm in the fused kernel's prologue.  Mode 1 keeps
+        # the 1.18 GB GEGLU intermediate of each of the 15 level-0 feed-forwards out of HBM (-35 GB per forward) and measures
+        # -1.0 ms per forward in place (A/B in one process); mode 2 is +9 ms (profiles/r03_e_*)
+        self.fused_ff = int(os.environ.get("EW_FUSED_FF", "1"))
         self._pos_cache = {}
         for hd, c in zip(cfg["num_attention_heads"], cfg["block_out_channels"]):
             if c // hd != 64:
