@@ -19,7 +19,8 @@
 //     registers).  W1's rows are packed so that the four outputs a lane owns per (value, gate) fragment pair are consecutive
 //     hidden indices -- the GEGLU result is already in A-fragment order;
 //   * the down-projection trails the up-projection by one chunk, so ONE barrier per chunk serves both the weight hand-over
-//     and the GEGLU exchange, and the GEGLU arithmetic / DMA requests of a chunk run in the shadow of MFMAs;
+//     and the GEGLU exchange; the GEGLU arithmetic of chunk c-1 (VALU: two transcendentals per element) is issued between the
+//     up-projection MFMAs of chunk c (FF_GSHADOW), the DMA requests between the down-projection MFMAs;
 //   * weights go through LDS one chunk image (W1 40 KB + W2 20 KB) per step, double-buffered, by LDS-DMA from host-packed
 //     images that are byte copies of the LDS layout (1 KB contiguous per DMA instruction; the XOR swizzles that make the
 //     ds_read_b128 fragment reads conflict-free are baked into the pack).  A chunk's image is requested a whole chunk before it is
@@ -46,7 +47,8 @@ constexpr int W1_TILE = KT * W1_KT;                                // 40 KB per 
 constexpr int W2_TILE = C * CH * 2;                                // 320 staged rows x 32 k x 2 B = 20 KB per chunk
 constexpr int HX_TILE = (BM / 16) * 64 * 16;                       // GEGLU exchange: 8 row fragments x 64 lanes x 16 B = 8 KB per chunk
 constexpr int LDS_W1 = 0, LDS_W2 = 2 * W1_TILE, LDS_HX = LDS_W2 + 2 * W2_TILE, LDS_B1 = LDS_HX + 2 * HX_TILE;
-constexpr int LDS_BYTES = LDS_B1 + 2 * HID * 2;                    // 80 + 40 + 16 + 5 KB
+constexpr int LDS_SCR = LDS_B1 + 2 * HID * 2;                     // 4 KB scratch slot (FF_GSHADOW: GEGLU output of the no-op first slice)
+constexpr int LDS_BYTES = LDS_SCR + 64 * NWV * 8 + 4096;                    // 80 + 40 + 16 + 5 KB
 constexpr int P1 = W1_TILE / 1024 / NWV;                           // W1 DMA pieces per wave and chunk (5); W2's 20 pieces are dealt round-robin
 constexpr int P2MAX = (W2_TILE / 1024 + NWV - 1) / NWV;            // 3 (waves 4-7 issue 2)
 constexpr int NJ2 = C / 16 / WAVES_N;                              // 10 output fragments per wave
@@ -70,6 +72,7 @@ struct FfP {
     const f16* ln_beta;
     const f16* addvec;
     int M, rows_per_group, ld_rowbias, n_tiles, add_rpg, stagger;
+    unsigned long long* trace;
     float c_acc, c_r1, c_r2, ln_eps;
 };
 
@@ -79,6 +82,15 @@ struct FfP {
 // loads are issued at the end of the previous tile), which drained the weight DMA right after it was requested: 3.4x slower.
 #define FF_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
 #define FF_PIN() __builtin_amdgcn_sched_barrier(0)
+#ifdef FF_TRACE           /* tools/experiments/exp39_ff_trace.py: s_memtime stamps of block 0, 8 per chunk and wave */
+#define FF_STAMP(k) do { if (p.trace && blockIdx.x == 0 && lane == 0 && cc < 4096) p.trace[((size_t)cc * NWV + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FF_STAMP(k) do {} while (0)
+#endif
+#ifndef FF_GSHADOW
+#define FF_GSHADOW 1      /* GEGLU of chunk c-1 between the up-projection MFMAs of chunk c (0: in phase 2, before the down-projection) */
+#endif
+#define FF_WAIT_VM0_LGKM0() __builtin_amdgcn_s_waitcnt(0x0070)
 #ifndef FF_ABL
 #define FF_ABL 0          /* ablation builds (tools/experiments): 1 no GEGLU math, 2 no DMA, 4 no epilogue, 8 no up-proj MFMA, 16 no down-proj MFMA */
 #endif
@@ -233,14 +245,35 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
 #pragma unroll
             for (int jj = 0; jj < NJ2; ++jj) acc2[rf][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
         f16x8 hf_old[RF] = {};                  // complete GEGLU A fragments of the previous chunk (zero before the tile's first)
+        f32x4 acc1p[RF][2] = {};                // FF_GSHADOW: up-projection accumulators of the previous chunk, waiting for their GEGLU
 
         // Software pipeline over the chunks of the tile.  Iteration c:
-        //   phase 1: up-projection of chunk c, this wave's half (40 MFMAs; W1 fragments two k-steps ahead)
-        //   barrier: W1 buffer cc & 1 and W2 / exchange buffers cc & 1 are free (down-projection of chunk c-2 is done); this wave's
-        //            pieces of W1(cc+1) and W2(cc-1), requested a chunk ago, have landed; the exchange halves of chunk c-1 are complete
-        //   phase 2: read the A fragments of chunk c-1 from the exchange buffer; GEGLU of chunk c (VALU) -> exchange buffer cc & 1;
-        //            down-projection of chunk c-1 (20 MFMAs); DMA requests for W1(cc+2) / W2(cc)
-        // The down-projection trails by one chunk; it is flushed after the last chunk of the tile.
+        //   phase 1: up-projection of chunk c, this wave's half (40 MFMAs; W1 fragments two k-steps ahead), with the GEGLU of chunk c-1
+        //            between the MFMAs -> exchange buffer (cc - 1) & 1
+        //   barrier: W1 buffer cc & 1 and W2 buffer cc & 1 are free (down-projection of chunk c-2 is done); this wave's pieces of
+        //            W1(cc+1) and W2(cc-1), requested a chunk ago, have landed; the exchange halves of chunk c-1 are complete
+        //   phase 2: read the A fragments of chunk c-1 from the exchange buffer; down-projection of chunk c-1 (20 MFMAs); DMA requests
+        //            for W1(cc+2) / W2(cc)
+        // The down-projection trails by one chunk; it is flushed (with the last chunk's GEGLU) after the last chunk of the tile.
+        // Segment trace (tools/experiments/exp39_ff_trace.py, -DFF_TRACE): a chunk is ~4300 clocks per wave against 1920 of MFMA pipe
+        // time per SIMD; the two waves of a SIMD share its VALU issue (2 x ~700 clocks of GEGLU) and the older one wins the arbitration,
+        // so the younger's phases run late and the older idles ~1100 clocks at each barrier.  A forced half-chunk offset between the two
+        // halves (ping-pong, two barriers per chunk) measured 12 % slower, scalar instead of packed fp32 GEGLU 3 % slower.
+        // bias + GEGLU of one row fragment of this wave's half chunk: fragments (value 2 wn, gate 2 wn + 1) -> hidden 8 fks + 4 wn + e
+        auto geglu_rf = [&](const f32x4 (&a)[2], const char* bb, char* dst) __attribute__((always_inline)) {
+            const f16x4 bv = *(const f16x4*)bb, bg = *(const f16x4*)(bb + 32);
+            const f32x4 va = a[0] + (f32x4){(float)bv[0], (float)bv[1], (float)bv[2], (float)bv[3]};
+            const f32x4 gg = a[1] + (f32x4){(float)bg[0], (float)bg[1], (float)bg[2], (float)bg[3]};
+#if FF_ABL & 1
+            const f32x2 o01 = (f32x2){va[0], va[1]} * (f32x2){gg[0], gg[1]};
+            const f32x2 o23 = (f32x2){va[2], va[3]} * (f32x2){gg[2], gg[3]};
+#else
+            const f32x2 o01 = ew_vgelu2((f32x2){va[0], va[1]}, (f32x2){gg[0], gg[1]});
+            const f32x2 o23 = ew_vgelu2((f32x2){va[2], va[3]}, (f32x2){gg[2], gg[3]});
+#endif
+            const f16x4 o4 = {(f16)o01[0], (f16)o01[1], (f16)o23[0], (f16)o23[1]};
+            *(f16x4*)dst = o4;
+        };
         for (int c = 0; c < NCH; ++c, ++cc) {
             const char* w1b = smem + LDS_W1 + (cc & 1) * W1_TILE;
             const char* w1n = smem + LDS_W1 + ((cc + 1) & 1) * W1_TILE;
@@ -250,6 +283,12 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
             for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc1[rf][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            FF_STAMP(0);
+            // FF_GSHADOW: the GEGLU of the PREVIOUS chunk (VALU, ~90 instructions with two transcendentals per element) is issued between
+            // the up-projection MFMAs of this one, one row fragment per half of the k loop; its halves go to exchange buffer (cc - 1) & 1 and are
+            // complete at this chunk's barrier.  On the first chunk of a tile the accumulators are zeros and the result goes to a scratch slot.
+            [[maybe_unused]] const char* bbp = smem + LDS_B1 + ((c > 0 ? c - 1 : 0) * 64 + 2 * wn * 16 + fks * 4) * 2;
+            [[maybe_unused]] char* hxp = c > 0 ? smem + LDS_HX + ((cc + 1) & 1) * HX_TILE + hx_off + wn * 8 : smem + LDS_SCR + tid * 8;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks + 2 < KS) {
@@ -266,12 +305,32 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
 #else
                         acc1[rf][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks % 3][j], xf[rf][ks], acc1[rf][j], 0, 0, 0);
 #endif
+#if FF_GSHADOW
+                static_assert(RF == 2 || RF == 4, "GEGLU slices");
+                if constexpr (RF == 2) {
+                    if (ks == 1) geglu_rf(acc1p[0], bbp, hxp);
+                    if (ks == 5) geglu_rf(acc1p[1], bbp, hxp + 1024);
+                } else {
+                    if (ks == 1 || ks == 3 || ks == 5 || ks == 7) geglu_rf(acc1p[(ks - 1) / 2], bbp, hxp + ((ks - 1) / 2) * 1024);
+                }
+#endif
                 FF_PIN();
             }
+#if FF_GSHADOW
+#pragma unroll
+            for (int rf = 0; rf < RF; ++rf) { acc1p[rf][0] = acc1[rf][0]; acc1p[rf][1] = acc1[rf][1]; }
+#endif
+            FF_STAMP(1);
+#if FF_GSHADOW
+            FF_WAIT_VM0_LGKM0();
+#else
             FF_WAIT_VM0();
+#endif
+            FF_STAMP(2);
             FF_FENCE();
             __builtin_amdgcn_s_barrier();
             FF_FENCE();
+            FF_STAMP(3);
             // ---- phase 2 (no branches: on the first chunk of a tile the exchange buffer holds zeros -- see the flush -- and past the
             // end of the block's work the W1 request / fragment reads touch buffers nobody reads again)
             if (c > 0) {
@@ -287,26 +346,16 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
             char* d1 = smem + LDS_W1 + (cc & 1) * W1_TILE + wave * (P1 * 1024);
             const f16* s2 = (const f16*)((const char*)p.w2p + (size_t)c * W2_TILE + wave * 1024) + lane * 8;
             char* d2 = smem + LDS_W2 + (cc & 1) * W2_TILE + wave * 1024;
-            // ---- bias + GEGLU of this wave's half: fragments (value 2 wn, gate 2 wn + 1) -> hidden 8 fks + 4 wn + e of the chunk
+#if !FF_GSHADOW
+            // ---- bias + GEGLU of this wave's half chunk -> exchange buffer cc & 1
             {
                 const char* bb = smem + LDS_B1 + (c * 64 + 2 * wn * 16 + fks * 4) * 2;
-                const f16x4 bv = *(const f16x4*)bb, bg = *(const f16x4*)(bb + 32);
 #pragma unroll
-                for (int rf = 0; rf < RF; ++rf) {
-                    const f32x4 va = acc1[rf][0] + (f32x4){(float)bv[0], (float)bv[1], (float)bv[2], (float)bv[3]};
-                    const f32x4 gg = acc1[rf][1] + (f32x4){(float)bg[0], (float)bg[1], (float)bg[2], (float)bg[3]};
-#if FF_ABL & 1
-                    const f32x2 o01 = (f32x2){va[0], va[1]} * (f32x2){gg[0], gg[1]};
-                    const f32x2 o23 = (f32x2){va[2], va[3]} * (f32x2){gg[2], gg[3]};
-#else
-                    const f32x2 o01 = ew_vgelu2((f32x2){va[0], va[1]}, (f32x2){gg[0], gg[1]});
-                    const f32x2 o23 = ew_vgelu2((f32x2){va[2], va[3]}, (f32x2){gg[2], gg[3]});
-#endif
-                    const f16x4 o4 = {(f16)o01[0], (f16)o01[1], (f16)o23[0], (f16)o23[1]};
-                    *(f16x4*)(smem + LDS_HX + (cc & 1) * HX_TILE + hx_off + rf * 1024 + wn * 8) = o4;
-                }
+                for (int rf = 0; rf < RF; ++rf) geglu_rf(acc1[rf], bb, smem + LDS_HX + (cc & 1) * HX_TILE + hx_off + rf * 1024 + wn * 8);
             }
+#endif
             FF_PIN();
+            FF_STAMP(4);
             // ---- down-projection of chunk c-1: one k-step x this wave's 10 output fragments x 2 row fragments
 #pragma unroll
             for (int g2 = 0; g2 < 2; ++g2) {
@@ -335,11 +384,23 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
                 }
                 FF_PIN();
             }
+            FF_STAMP(5);
         }
         // ---- flush: down-projection of the tile's last chunk (its W2 image was requested in the last phase 2, its exchange halves
         // were written there); the exchange buffer the NEXT tile's first chunk will read as "chunk -1" is zeroed
         {
-            FF_WAIT_VM0();
+#if FF_GSHADOW
+            {   // GEGLU of the tile's last chunk (nothing left to hide it under)
+                const char* bb = smem + LDS_B1 + ((NCH - 1) * 64 + 2 * wn * 16 + fks * 4) * 2;
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf) {
+                    geglu_rf(acc1p[rf], bb, smem + LDS_HX + ((cc + 1) & 1) * HX_TILE + hx_off + rf * 1024 + wn * 8);
+                    acc1p[rf][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    acc1p[rf][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#endif
+            FF_WAIT_VM0_LGKM0();
             FF_FENCE();
             __builtin_amdgcn_s_barrier();
             FF_FENCE();
@@ -433,6 +494,11 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
 
 }  // namespace
 
+#ifdef FF_TRACE
+static unsigned long long* g_ff_trace = nullptr;
+extern "C" void ew_ff_set_trace(void* buf) { g_ff_trace = (unsigned long long*)buf; }
+#endif
+
 // Host-side layout contract of the packs (evoworld_amd/ops.py: ff_pack builds them with torch index ops):
 //   w1p  [40 chunks][5 K-tiles][64 staged rows][8 slots][8 halves]: staged row r = 16 j + i, j = 2h + vg (vg: 0 value, 1 gate),
 //        i = 4 fks + e  <-  proj row (vg ? HID : 0) + 32 c + 8 fks + 4 h + e;   slot sl holds k = 64 kt + 8 (sl ^ (r & 7)) .. +8
@@ -460,6 +526,11 @@ extern "C" ew_status ew_ff_geglu320_f16(const ew_ff_args* a, void* stream) {
     p.x_lo = (const int8_t*)a->x_lo; p.ln_gamma = (const f16*)a->ln_gamma; p.ln_beta = (const f16*)a->ln_beta;
     p.addvec = (const f16*)a->addvec; p.add_rpg = a->add_rows_per_group >= 1 ? a->add_rows_per_group : 1; p.ln_eps = a->ln_eps;
     const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
+#ifdef FF_TRACE
+    p.trace = g_ff_trace;
+#else
+    p.trace = nullptr;
+#endif
     static const int stagger_env = [] { const char* e = getenv("EW_FF_STAGGER"); return e ? atoi(e) : 1; }();
     p.stagger = stagger_env;
     const bool lo = a->r1_lo || a->r2_lo || a->out_lo || a->x_lo;
