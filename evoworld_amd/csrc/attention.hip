@@ -18,6 +18,13 @@
 #include "common.h"
 #include <type_traits>
 
+// Softmax scale-and-shift as two plain v_fma_f32 instead of one v_pk_fma_f32 (round 3): at SIMD level a packed fp32 instruction costs two
+// plain issues anyway, and beside MFMAs it costs MORE than that (tools/experiments/mb_mfma_valu.hip: 8 MFMA + 32 v_pk_fma 308 ns,
+// 8 MFMA + 64 v_fma 255 ns per iteration).  Bit-identical results, 840 -> 855 TF/s at the level-0 shape.  The file is compiled with
+// -fno-slp-vectorize so that hipcc does not re-pack them.
+#ifndef EW_ATTN_SCALAR_FMA
+#define EW_ATTN_SCALAR_FMA 1
+#endif
 namespace {
 
 __device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
@@ -180,8 +187,12 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = g2 * 8 + e * 2;
+#if EW_ATTN_SCALAR_FMA
+                    const float t[2] = {fmaf(sacc[blk][r], sl2, nm2[0]), fmaf(sacc[blk][r + 1], sl2, nm2[0])};
+#else
                     const f32x2 sv = {sacc[blk][r], sacc[blk][r + 1]};
                     const f32x2 t = __builtin_elementwise_fma(sv, sl22, nm2);          // v_pk_fma_f32: two scores per VALU issue
+#endif
                     const h2_t ph = __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]));
                     const h2_t one = {(__fp16)1.0f, (__fp16)1.0f};
                     l_run = __builtin_amdgcn_fdot2(ph, one, l_run, false);
