@@ -169,3 +169,31 @@ def per_timestep_floor(steps_list=(2, 3, 25)):
 
 if __name__ == "__main__" and "--per-timestep" in sys.argv:
     per_timestep_floor()
+
+
+def norm_input_ablation():
+    """Round 3: what would it cost to feed the normalisation layers fp16-rounded inputs (i.e. to let GroupNorm statistics / apply or
+    LayerNorm read the hi half of the split stream only and save its lo8 byte)?  On top of the fp16-operand floor (tiny config):
+    GroupNorm inputs +0.42e-6 squared rel-L2 (7.49e-4 -> 9.92e-4: the whole remaining budget -- GroupNorm keeps reading hi + lo8, and
+    ops.groupnorm(stats_hi_only=...) stays off), LayerNorm inputs +0.025e-6 (7.66e-4: affordable, worth ~0.7 ms; not taken)."""
+    torch.manual_seed(0)
+    cfg = tiny_config()
+    model = UNetRef(**cfg).eval()
+    g = torch.Generator().manual_seed(1)
+    model.load_state_dict({k: v.half().float() for k, v in random_state_dict({**DEFAULT_CONFIG, **cfg}, 0).items()}, strict=True)
+    T, h, w = cfg["num_frames"], 16, 32
+    x = torch.randn(2, T, 18, h, w, generator=g)
+    ehs = torch.randn(2, 1, cfg["cross_attention_dim"], generator=g)
+    ehs[0] = 0
+    inputs = (x, torch.tensor(1.234), ehs, torch.tensor([[6.0, 127.0, 0.02]] * 2))
+    mm = (torch.nn.Conv2d, torch.nn.Conv3d, torch.nn.Linear)
+    ref = run(model, inputs)
+    base = rel(run(model, inputs, pre=r16, kinds_pre=mm), ref)
+    print(f"operands only: {base:.3e}")
+    for kinds, name in (((torch.nn.GroupNorm,), "GroupNorm inputs"), ((torch.nn.LayerNorm,), "LayerNorm inputs")):
+        e = rel(run(model, inputs, pre=r16, kinds_pre=mm + kinds), ref)
+        print(f"  + fp16 {name:18s}: {e:.3e}   added squared rel-L2 {(e * e - base * base) * 1e6:.3f}e-6")
+
+
+if __name__ == "__main__" and "--norm-inputs" in sys.argv:
+    norm_input_ablation()
