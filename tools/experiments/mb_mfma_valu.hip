@@ -14,6 +14,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define VFMA(x, a, b) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(x) : "v"(a), "v"(b))
 #define VEXP(x) asm volatile("v_exp_f32 %0, %0" : "+v"(x))
 #define DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define VMAD64(d, a, b, c) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c) : "vcc")
+#define VLSHLADD64(d, a, c) asm volatile("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(d) : "v"(a), "v"(c))
 #define VPK(x, a, b) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(x) : "v"(a), "v"(b))
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -32,6 +34,9 @@ __global__ __launch_bounds__(512, 2) void k(float* out, int iters) {
     f32x2 y[8];
     for (int i = 0; i < 16; ++i) x[i] = threadIdx.x + i;
     for (int i = 0; i < 8; ++i) y[i] = (f32x2){(float)i, (float)threadIdx.x};
+    int ia[4];
+    long long ip[4], ibase = (long long)(size_t)out;
+    for (int i = 0; i < 4; ++i) { ia[i] = threadIdx.x * 3 + i; ip[i] = i; }
     const float c0 = 1.0001f, c1 = 0.5f;
     const f32x2 p0 = {1.0001f, 0.9999f}, p1 = {0.5f, 0.25f};
     for (int it = 0; it < iters; ++it) {
@@ -43,6 +48,8 @@ __global__ __launch_bounds__(512, 2) void k(float* out, int iters) {
                 if (KIND == 3) { if (v == 0) { if (g == 0) DSR(ld[0], laddr, 0); if (g == 1) DSR(ld[1], laddr, 1024); if (g == 2) DSR(ld[2], laddr, 2048); if (g == 3) DSR(ld[3], laddr, 3072);
                                                if (g == 4) DSR(ld[4], laddr, 0); if (g == 5) DSR(ld[5], laddr, 1024); if (g == 6) DSR(ld[6], laddr, 2048); if (g == 7) DSR(ld[7], laddr, 3072); }
                                  if (v == 1) { if (g == 0) DSR(ld[4], laddr, 16384); if (g == 2) DSR(ld[5], laddr, 17408); if (g == 4) DSR(ld[6], laddr, 18432); if (g == 6) DSR(ld[7], laddr, 19456); } }
+                else if (KIND == 4) { long long t; VMAD64(t, ia[g & 3], iters, ibase); VLSHLADD64(ip[g & 3], t, ibase); }
+                else if (KIND == 5) { VLSHLADD64(ip[g & 3], ip[g & 3], ibase); }
                 else if (KIND == 0) VFMA(x[(g * (NV / 8) + v) & 15], c0, c1);
                 else if (KIND == 1) VEXP(x[(g * (NV / 8) + v) & 15]);
                 else VPK(y[(g * (NV / 8) + v) & 7], p0, p1);
@@ -56,6 +63,7 @@ __global__ __launch_bounds__(512, 2) void k(float* out, int iters) {
     for (int i = 0; i < 16; ++i) s += x[i];
     for (int i = 0; i < 8; ++i) s += y[i][0] + y[i][1];
     if (KIND == 3) for (int i = 0; i < 8; ++i) s += ld[i][0] + ld[i][2];
+    if (KIND >= 4) for (int i = 0; i < 4; ++i) s += (float)ip[i];
     if (s == 12345.678f) out[0] = s;
 }
 
@@ -96,6 +104,10 @@ int main() {
     ROW(8, 8, 3, "8 MFMA + 8 ds_read_b128");
     ROW(0, 16, 3, "12 ds_read_b128 only");
     ROW(8, 16, 3, "8 MFMA + 12 ds_read_b128");
+    ROW(0, 8, 4, "8 x (v_mad_i64_i32 + v_lshl_add_u64) only");
+    ROW(8, 8, 4, "8 MFMA + 8 x (mad_i64 + lshl_add_u64)");
+    ROW(0, 8, 5, "8 v_lshl_add_u64 only");
+    ROW(8, 8, 5, "8 MFMA + 8 v_lshl_add_u64");
     ROW(0, 32, 2, "32 v_pk_fma_f32 only");
     ROW(8, 32, 2, "8 MFMA + 32 v_pk_fma_f32");
     return 0;
