@@ -21,9 +21,6 @@
 
 extern char g_gemm_last_kernel[64];
 
-#ifndef EW3_ROWOFF
-#define EW3_ROWOFF 1
-#endif
 namespace {
 
 #define EW3_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
@@ -151,10 +148,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     int ld_w = 0, ld_kt = 0, ld_k1 = 0, ld_tap = 0, ld_cc = 0;   // ld_kt == ld_k1: the next stage_begin opens work item ld_w
     int a_ctr[GA];                         // centre-tap pixel (row) index in the source tensors
     int a_mask[GA];                        // bits 0..8 tap validity, bits 16..27 upsample (dy,dx) codes
-#if EW3_ROWOFF
-    unsigned a_row[GA];                    // a_ctr * (row stride of the source being staged) + this lane's 16-byte slot, in elements
-    int a_row_ld = -1;                     // the row stride a_row was formed with (-1: stale: new tile)
-#endif
     const f16* b_ptr0 = p.w;               // W row of this lane's first piece (+ its 16-byte slot); piece j adds j*NW*8 rows
 
     auto loader_new_tile = [&](const int id) __attribute__((always_inline)) {
@@ -229,9 +222,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
             EW3_GET_ITEM(ld_w, id, k0, ld_k1);
             ++ld_w;
             loader_new_tile(id);
-#if EW3_ROWOFF
-            a_row_ld = -1;
-#endif
             ld_kt = k0;
             const int chunk = k0 / NTAP;                                   // K order: channel chunk major, tap minor
             ld_tap = k0 - chunk * NTAP;
@@ -248,16 +238,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
         if constexpr (MODE == EW_A_CONV3X3) dpix = (st_tap / 3 - 1) * p.w_in + (st_tap % 3 - 1);
         else if constexpr (MODE == EW_A_CONVT3) dpix = (st_tap - 1) * p.tP;
         st_dl = (long long)dpix * st_ld + st_ch;
-#if EW3_ROWOFF
-        // the 64-bit row * stride product of every piece address (v_mad_i64_i32, a multi-pass VALU instruction beside the MFMAs, four
-        // per wave and K-tile) is formed once per tile and source instead; a piece address is then base + zext(a_row + tap / chunk
-        // offset): two plain VALU.  Offsets fit 32 bits (ew_gemm3_wants checks the A operands).
-        if (a_row_ld != st_ld) {
-            a_row_ld = st_ld;
-#pragma unroll
-            for (int i = 0; i < GA; ++i) a_row[i] = (unsigned)a_ctr[i] * (unsigned)st_ld + (unsigned)(slot * 8);
-        }
-#endif
         st_koff = (size_t)ld_kt * BK;
         // K order: channel-chunk major, tap minor (the taps of a 64-channel chunk re-hit the same lines in L2 / TCP)
         if (++ld_tap == NTAP) { ld_tap = 0; ld_cc += BK; }
@@ -266,11 +246,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     auto stage_piece = [&](int k) __attribute__((always_inline)) {     // k is a compile-time constant after unrolling
         if (k < GA) {
             const int i = k;
-#if EW3_ROWOFF
-            const f16* src = st_base + (size_t)(unsigned)(a_row[i] + (unsigned)(int)st_dl);      // wraps only where the tap is masked out
-#else
             const f16* src = st_base + ((long long)a_ctr[i] * st_ld + (st_dl + slot * 8));
-#endif
             if constexpr (MODE == EW_A_CONV3X3) {
                 if (p.upsample) {                                           // per-row deltas (nearest-x2 source coordinates)
                     const int dc = a_mask[i] >> 16;
@@ -906,13 +882,6 @@ bool EW3_NAME(ew_gemm3_wants)(const GemmP& p) {
     const long long ld_max = max((long long)p.ld_out, max((long long)p.ld_r1, (long long)p.ld_r2));
     if ((long long)p.M * ld_max * 2 >= (1LL << 32)) return false;
     if (p.rowbias && ((long long)p.M / max(1, p.rows_per_group) + 2) * p.ld_rowbias * 2 >= (1LL << 32)) return false;
-#if EW3_ROWOFF
-    {   // the loader forms A element offsets (row * stride + channel) in 32 bits
-        long long a_rows = p.M;
-        if (p.mode == EW_A_CONV3X3) a_rows = (long long)(p.M / max(1, p.h_out * p.w_out)) * p.h_in * p.w_in;
-        if ((a_rows + 2) * max(p.lda, p.lda2) + p.c1 + p.c2 >= (1LL << 32)) return false;
-    }
-#endif
     // one tile column and a short K: 1800 tiles = 7.03 rounds over 256 CUs cost 8, and the residual-carrying epilogue is
     // store-bound anyway -- generation 2's 256x160 tiles (14.06 -> 15 rounds) measured 5-10 % faster there
     static const int short_rule = getenv("EW_G3_SHORT") ? atoi(getenv("EW_G3_SHORT")) : 0;     // A/B hook: 1 = gen3 also there
