@@ -207,7 +207,7 @@ def test_full_size_clip_vs_oracle():
     from evoworld_amd.unet import DEFAULT_CONFIG, UNetSpatioTemporalConditionModel, random_state_dict
     from oracle.unet_ref import UNetSpatioTemporalConditionModelRef
     steps = int(os.environ["EW_FULL_PARITY_STEPS"])
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    torch.set_num_threads(min(int(os.environ.get("EW_ORACLE_THREADS", "32")), os.cpu_count() or 1))
     cfg = dict(in_channels=18, out_channels=4, block_out_channels=(320, 640, 1280, 1280), addition_time_embed_dim=256,
                projection_class_embeddings_input_dim=768, layers_per_block=2, cross_attention_dim=1024,
                num_attention_heads=(5, 10, 20, 20), num_frames=25)

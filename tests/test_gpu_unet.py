@@ -126,7 +126,7 @@ def test_unet_full_size_forward_vs_oracle():
                projection_class_embeddings_input_dim=768, layers_per_block=2, cross_attention_dim=1024,
                num_attention_heads=(5, 10, 20, 20), num_frames=25)           # evoworld/trainer/unet_plucker.py:69-94, in_channels 18
     B, T, h, w = 2, 25, 72, 128
-    torch.set_num_threads(min(32, __import__("os").cpu_count() or 1))
+    torch.set_num_threads(min(int(__import__("os").environ.get("EW_ORACLE_THREADS", "32")), __import__("os").cpu_count() or 1))
     m, ref, x, ehs, ids = _setup(cfg, B, T, h, w, seed=7)
     t = torch.tensor(1.6377)
     gt = {}
