@@ -46,12 +46,15 @@ class _FakeCLIP:
         return type("O", (), {"image_embeds": v})
 
 
-def _oracle_loop(ref, lat0, il, ehs, pl, T, steps, mask_mem=False, trace=None):
+def _oracle_loop(ref, lat0, il, ehs, pl, T, steps, mask_mem=False, trace=None, start=0, lat_start=None, stop_after=None, on_step=None):
+    """fp32 CPU oracle of the denoise loop.  start / lat_start resume it from the latents after step `start` (a checkpoint of an
+    earlier call: the full-size 25-step run is longer than one gpurun call), stop_after ends it early, on_step(i, lat) is called after
+    every step (checkpoint writer)."""
     from evoworld_amd.scheduler import EulerDiscreteScheduler
     from oracle.reproject_ref import euler_cfg_step_ref
     s = EulerDiscreteScheduler()
     s.set_timesteps(steps)
-    lat = lat0 * s.init_noise_sigma
+    lat = lat0 * s.init_noise_sigma if lat_start is None else lat_start
     il2 = torch.cat([torch.zeros_like(il), il])
     if mask_mem:
         il2[:, 1:] = 0
@@ -59,13 +62,15 @@ def _oracle_loop(ref, lat0, il, ehs, pl, T, steps, mask_mem=False, trace=None):
     e2 = torch.cat([torch.zeros_like(ehs), ehs])
     ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
     guid = torch.linspace(1.0, 3.0, T)
-    for i in range(steps):
+    for i in range(start, steps if stop_after is None else min(steps, stop_after)):
         sig, sign = float(s.sigmas[i]), float(s.sigmas[i + 1])
         x = torch.cat([torch.cat([lat, lat]) / (sig ** 2 + 1) ** 0.5, cond], dim=2)
         eps = ref(x, s.timesteps[i], e2, ids)
         lat = euler_cfg_step_ref(eps[0:1], eps[1:2], lat, guid, sig, sign)
         if trace is not None:
             trace.append(lat.clone())
+        if on_step is not None:
+            on_step(i, lat)
     return lat
 
 
@@ -225,16 +230,33 @@ def test_full_size_clip_vs_oracle():
                           latents=lat0, output_type="latent", plucker_embedding=pl, image_latents=il, image_embeddings=ehs,
                           callback_on_step_end=lambda p, i, t, kw: got.append(kw["latents"].detach().cpu().clone()) or {}).frames
 
+    # EW_FULL_PARITY_CKPT=<file in the tree>: resume the oracle from the latents an earlier call saved (gpurun caps a call at 3600 s and
+    # the oracle needs ~172 s per step); EW_FULL_PARITY_STOP=<n>: end this call after oracle step n.  Every step's latents go to
+    # gpurun_out/clip_oracle_ckpt.pt (3.7 MB, merged back by gpurun).
+    start, lat_start = 0, None
+    ck = os.environ.get("EW_FULL_PARITY_CKPT")
+    if ck and os.path.exists(ck):
+        st = torch.load(ck)
+        assert st["steps"] == steps
+        start, lat_start = st["done"], st["lat"]
+        print(f"full-size clip: oracle resumed after step {start}", flush=True)
+    stop = int(os.environ.get("EW_FULL_PARITY_STOP", "0")) or None
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+
     class _Trace(list):                                  # print the curve as the oracle goes (an hour of host time at 25 steps)
         def append(self, lat):
             super().append(lat)
-            i = len(self) - 1
+            i = start + len(self) - 1
             print(f"full-size clip step {i + 1:2d}/{steps}: rel-L2 {rel_l2(got[i], lat):.3e}  ({time.time() - t0:.0f} s)", flush=True)
             sys.stdout.flush()
     t0 = time.time()
     want = _Trace()
     with torch.no_grad():
-        final = _oracle_loop(ref, lat0, il, ehs, pl, T, steps, trace=want)
+        final = _oracle_loop(ref, lat0, il, ehs, pl, T, steps, trace=want, start=start, lat_start=lat_start, stop_after=stop,
+                             on_step=lambda i, lat: torch.save({"steps": steps, "done": i + 1, "lat": lat}, os.path.join(out_dir, "clip_oracle_ckpt.pt")))
+    if stop is not None and stop < steps:
+        pytest.skip(f"stopped after oracle step {stop} of {steps} (EW_FULL_PARITY_STOP); checkpoint in gpurun_out/clip_oracle_ckpt.pt")
     e = rel_l2(out.cpu(), final)
     print(f"FULL-SIZE clip ({steps} steps, T=25, 72x128 latents, 1.52 B parameters) final rel-L2 {e:.3e}", flush=True)
     assert torch.isfinite(out).all()
