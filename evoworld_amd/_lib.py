@@ -12,12 +12,12 @@ from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EW_LIB_PATH") or os.path.join(_HERE, "libevoworld_hip.so")   # EW_LIB_PATH: ablation builds (tools/)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol declared in include/evoworld_hip.h
 SYMBOLS = [
     "ew_abi_version", "ew_last_error", "ew_gemm_f16", "ew_set_gemm_generation", "ew_get_gemm_generation", "ew_set_gemm_debug", "ew_gemm_last_kernel", "ew_gemm_streamk_status", "ew_gemm_streamk_init", "ew_ff_geglu320_f16", "ew_groupnorm_workspace_floats", "ew_groupnorm_stats_f16", "ew_groupnorm_finalize", "ew_groupnorm_apply_f16",
-    "ew_layernorm_f16", "ew_attn_spatial_f16", "ew_attn_temporal_f16", "ew_nchw_f32_to_nhwc_f16",
+    "ew_layernorm_f16", "ew_attn_spatial_f16", "ew_attn_spatial_log2_f16", "ew_attn_temporal_f16", "ew_nchw_f32_to_nhwc_f16",
     "ew_nhwc_f16_to_nchw_f32", "ew_softmax_rows_f16", "ew_time_conv3_f32", "ew_euler_cfg_step", "ew_plucker_embed", "ew_cube2equi_gather",
     "ew_depth_unproject", "ew_select_workspace_bytes", "ew_select_kth_f32", "ew_filter_compact_workspace_bytes",
     "ew_filter_compact", "ew_splat_cubemap", "ew_splat_resolve", "ew_equi2pers", "ew_resize_aa_u8",
@@ -87,6 +87,7 @@ def load():
         "ew_ff_geglu320_f16": [ctypes.POINTER(FfArgs), P],
         "ew_layernorm_f16": [P, P, P, I, P, P, P, P, P, I, I, F, P],
         "ew_attn_spatial_f16": [P, P, P, P, I, I, I, I, LL, I, F, P],
+        "ew_attn_spatial_log2_f16": [P, P, P, P, I, I, I, I, LL, I, P],
         "ew_attn_temporal_f16": [P, P, P, P, I, I, I, I, I, I, F, P],
         "ew_nchw_f32_to_nhwc_f16": [P, P, I, I, I, I, I, I, F, P],
         "ew_nhwc_f16_to_nchw_f32": [P, P, I, I, I, I, I, P],

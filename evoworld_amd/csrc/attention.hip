@@ -30,7 +30,16 @@ namespace {
 __device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
 typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+// PRE = true (round 4, ew_attn_spatial_log2_f16): q and k arrive PRE-SCALED -- the projection GEMM's epilogue multiplied both by
+// sqrt(scale * log2 e) in fp32 before its single rounding to fp16 -- so q.k is already the exponent in log2 units, and the running max is
+// subtracted by the MFMA itself: the first MFMA of a score block takes C = (-m, ..., -m) (a 16-register tuple that only changes when the
+// deferred max is raised) instead of C = 0.  The per-score v_fma_f32 (32 of the ~120 VALU instructions of a 64-key tile in this VALU-bound
+// loop) disappears; a raise (rare) subtracts the increment from the tile's scores afterwards.
+#ifndef EW_ATTN_PRE_BLOCKS
+#define EW_ATTN_PRE_BLOCKS 3   /* 168 VGPRs (3 dwords of scratch outside the tile loop) -> 3 waves per SIMD: 926 vs 875 TF/s at the level-0 shape */
+#endif
+template <bool PRE>
+__global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatial_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                                const f16* __restrict__ vt, f16* __restrict__ o, int S,
                                                                int heads, int ld_qk, long long ld_vt, int ld_o, float sl2,
                                                                int n_qtiles) {
@@ -104,7 +113,10 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     f32x16 oacc[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = PRE ? 0.f : -INFINITY, l_run = 0.f;
+    f32x16 negm;                            // PRE: C operand of the first score MFMA = -m_run in every element (0 until the first tile's raise)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negm[i] = 0.f;
 
     // fragment byte offsets inside a tile, shared by the K tile (row = key) and the V^T tile (row = d): row-block b (0/1),
     // 16-byte slot pair s -> (b*32+lq)*128 + (((2s+lh) ^ swz(row)) << 4).  Precomputed: the loop was VALU-bound
@@ -138,8 +150,12 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         f32x16 sacc[2];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
+            if constexpr (PRE) {
+                sacc[blk] = negm;
+            } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[blk][i] = 0.f;
+                for (int i = 0; i < 16; ++i) sacc[blk][i] = 0.f;
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const f16x8 kf = *(const f16x8*)(kb + foff[blk][s]);
@@ -163,9 +179,24 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 #pragma unroll
         for (int r = 0; r < 16; r += 2) tmax = fmaxf(fmaxf(tmax, sacc[1][r]), sacc[1][r + 1]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mt = tmax * sl2;
         // deferred max: raise the running max only when this tile exceeds it by > 2^DEFER_THR (P stays <= 2^6, exact in
         // fp16's relative precision); the O / l rescale (34 VALU per lane) is skipped on almost every tile.
+        if constexpr (PRE) {
+            // the scores are already s - m_run: tmax is the increment.  The first tile always sets the max (m_run starts at 0, not -inf:
+            // an infinite C operand would poison the MFMA), whatever its sign.
+            const bool raise = tmax > (j == 0 ? -INFINITY : DEFER_THR);
+            if (__any(raise)) {
+                const float delta = raise ? tmax : 0.f;
+                const float alpha = j == 0 ? 1.f : exp2f(-delta);           // nothing accumulated yet on the first tile (exp2(-delta) may be inf)
+                m_run += delta;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { sacc[0][i] -= delta; sacc[1][i] -= delta; negm[i] = -m_run; }
+            }
+        } else {
+        const float mt = tmax * sl2;
         const bool raise = mt > m_run + DEFER_THR;
         if (__any(raise)) {
             const float m_new = raise ? mt : m_run;
@@ -174,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
             l_run *= alpha;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+        }
         }
         // P = exp2(S*c - m) -> fp16 pairs (round-toward-zero pack: one instruction per pair; its bias cancels because the
         // normaliser l below is accumulated from the SAME rounded values, with v_dot2)
@@ -188,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
                 for (int e = 0; e < 4; ++e) {
                     const int r = g2 * 8 + e * 2;
 #if EW_ATTN_SCALAR_FMA
-                    const float t[2] = {fmaf(sacc[blk][r], sl2, nm2[0]), fmaf(sacc[blk][r + 1], sl2, nm2[0])};
+                    const float t[2] = {PRE ? sacc[blk][r] : fmaf(sacc[blk][r], sl2, nm2[0]), PRE ? sacc[blk][r + 1] : fmaf(sacc[blk][r + 1], sl2, nm2[0])};
 #else
                     const f32x2 sv = {sacc[blk][r], sacc[blk][r + 1]};
                     const f32x2 t = __builtin_elementwise_fma(sv, sl22, nm2);          // v_pk_fma_f32: two scores per VALU issue
@@ -494,19 +526,34 @@ __global__ __launch_bounds__(256) void attn_temporal64_kernel(const f16* __restr
 
 }  // namespace
 
-extern "C" ew_status ew_attn_spatial_f16(const void* q, const void* k, const void* vt, void* o, int n_seq, int S, int heads,
-                                         int ld_qk, long long ld_vt, int ld_o, float scale, void* stream) {
-    EW_REQUIRE(q && k && vt && o, "ew_attn_spatial_f16: null pointer");
-    EW_REQUIRE(n_seq > 0 && S > 0 && heads > 0, "ew_attn_spatial_f16: bad shape");
-    EW_REQUIRE(S % 8 == 0, "ew_attn_spatial_f16: S must be a multiple of 8 (S=%d)", S);
-    EW_REQUIRE(ld_qk % 8 == 0 && ld_vt % 8 == 0 && ld_o % 4 == 0, "ew_attn_spatial_f16: strides must be 16-byte aligned");
+static ew_status attn_spatial_launch(const void* q, const void* k, const void* vt, void* o, int n_seq, int S, int heads, int ld_qk,
+                                     long long ld_vt, int ld_o, float scale, bool pre, void* stream, const char* name) {
+    EW_REQUIRE(q && k && vt && o, "%s: null pointer", name);
+    EW_REQUIRE(n_seq > 0 && S > 0 && heads > 0, "%s: bad shape", name);
+    EW_REQUIRE(S % 8 == 0, "%s: S must be a multiple of 8 (S=%d)", name, S);
+    EW_REQUIRE(ld_qk % 8 == 0 && ld_vt % 8 == 0 && ld_o % 4 == 0, "%s: strides must be 16-byte aligned", name);
     const int n_qtiles = ew_cdiv(S, 128);
     const long long nblk = (long long)n_seq * heads * n_qtiles;
-    EW_REQUIRE(nblk < 0x7fffffffLL, "ew_attn_spatial_f16: grid too large");
-    hipLaunchKernelGGL(attn_spatial_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const f16*)q,
-                       (const f16*)k, (const f16*)vt, (f16*)o, S, heads, ld_qk, ld_vt, ld_o,
-                       scale * 1.4426950408889634f, n_qtiles);
-    return ew_check_launch("ew_attn_spatial_f16");
+    EW_REQUIRE(nblk < 0x7fffffffLL, "%s: grid too large", name);
+    if (pre)
+        hipLaunchKernelGGL(attn_spatial_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const f16*)q,
+                           (const f16*)k, (const f16*)vt, (f16*)o, S, heads, ld_qk, ld_vt, ld_o, 1.0f, n_qtiles);
+    else
+        hipLaunchKernelGGL(attn_spatial_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const f16*)q,
+                           (const f16*)k, (const f16*)vt, (f16*)o, S, heads, ld_qk, ld_vt, ld_o,
+                           scale * 1.4426950408889634f, n_qtiles);
+    return ew_check_launch(name);
+}
+
+extern "C" ew_status ew_attn_spatial_f16(const void* q, const void* k, const void* vt, void* o, int n_seq, int S, int heads,
+                                         int ld_qk, long long ld_vt, int ld_o, float scale, void* stream) {
+    return attn_spatial_launch(q, k, vt, o, n_seq, S, heads, ld_qk, ld_vt, ld_o, scale, false, stream, "ew_attn_spatial_f16");
+}
+
+// q and k pre-scaled by sqrt(scale * log2 e) each (the caller's projection GEMM: ew_gemm_args.c_acc): softmax_2(q k^T) v
+extern "C" ew_status ew_attn_spatial_log2_f16(const void* q, const void* k, const void* vt, void* o, int n_seq, int S, int heads,
+                                              int ld_qk, long long ld_vt, int ld_o, void* stream) {
+    return attn_spatial_launch(q, k, vt, o, n_seq, S, heads, ld_qk, ld_vt, ld_o, 1.0f, true, stream, "ew_attn_spatial_log2_f16");
 }
 
 extern "C" ew_status ew_attn_temporal_f16(const void* q, const void* k, const void* v, void* o, int B, int T, int S,

@@ -221,6 +221,17 @@ def attn_spatial(q, k, vt, o, n_seq, S, heads, ld_qk, ld_vt, ld_o, scale=0.125):
     return o
 
 
+QK_LOG2_PRESCALE = (0.125 * 1.4426950408889634) ** 0.5    # sqrt(head_dim^-0.5 * log2 e), head_dim 64: c_acc of the q|k projection
+
+
+def attn_spatial_log2(q, k, vt, o, n_seq, S, heads, ld_qk, ld_vt, ld_o):
+    """q, k pre-scaled by QK_LOG2_PRESCALE each (projection epilogue): the kernel's MFMA subtracts the running max itself."""
+    lib = _lib.load()
+    _lib.check(lib.ew_attn_spatial_log2_f16(_ptr(q), _ptr(k), _ptr(vt), _ptr(o), n_seq, S, heads, ld_qk, ld_vt, ld_o, _stream()),
+               "ew_attn_spatial_log2_f16")
+    return o
+
+
 def attn_temporal(q, k, v, o, B, T, S, heads, ld, ld_o, scale=0.125):
     lib = _lib.load()
     _lib.check(lib.ew_attn_temporal_f16(_ptr(q), _ptr(k), _ptr(v), _ptr(o), B, T, S, heads, ld, ld_o, scale, _stream()),

@@ -225,6 +225,9 @@ class UNetSpatioTemporalConditionModel:
         # BASELINE.json configs[4]: q / k / v projections on the fp8 (e4m3) MFMA path (per-token activation scales,
         # per-output-channel weight scales); off by default -- it changes the numerics contract (tests/test_gpu_fp8.py)
         self.qkv_fp8 = bool(config.get("qkv_fp8", os.environ.get("EW_QKV_FP8", "0") == "1"))
+        # round 4: q|k projections carry sqrt(scale * log2 e) in their epilogue and the attention kernel's MFMA subtracts the running max
+        # (ew_attn_spatial_log2_f16); EW_ATTN_LOG2=0 restores the scale-and-shift form
+        self.attn_log2 = os.environ.get("EW_ATTN_LOG2", "1") == "1"
         # conv1 output of every resblock (the GroupNorm input between the two 3x3 convs) carried split too: in the per-tensor
         # ablation (tests/analysis_fp16_floor.py --per-tensor, tag res_h1) its fp16 rounding was the largest storage term left
         # (0.15e-6 of squared rel-L2 against 0.56e-6 for fp16 MFMA operands alone); EW_SPLIT_H1=0 restores the plain fp16 tensor
@@ -520,11 +523,14 @@ class UNetSpatioTemporalConditionModel:
             qk = ops.gemm_fp8(n8, nsc, *d["s_qk8"])
             vt = ops.gemm_fp8(d["s_v8"][0], d["s_v8"][1], n8, nsc)   # V^T = W_v X^T: operand roles swapped
         else:
-            qk = ops.linear(n1, d["s_qk"])
+            qk = ops.linear(n1, d["s_qk"], c_acc=ops.QK_LOG2_PRESCALE if self.attn_log2 else 1.0)
             vt = torch.empty(C, rows, dtype=torch.float16, device=dev)
             ops.gemm(d["s_v"], n1, vt, M=C, N=rows, c1=C, lda=C)      # V^T = W_v X^T (swapped operands)
         ao = torch.empty(rows, C, dtype=torch.float16, device=dev)
-        ops.attn_spatial(qk, qk[:, C:], vt, ao, N, S, t.heads, 2 * C, rows, C)
+        if self.attn_log2 and not self.qkv_fp8:
+            ops.attn_spatial_log2(qk, qk[:, C:], vt, ao, N, S, t.heads, 2 * C, rows, C)
+        else:
+            ops.attn_spatial(qk, qk[:, C:], vt, ao, N, S, t.heads, 2 * C, rows, C)
         del qk, vt
         # attn1 out-proj + residual + folded single-token cross attention (per batch row)
         h = ops.linear(ao, d["s_ow"], d["s_ob"], out=self._res(rows, C, dev), rowbias=cv_s, rows_per_group=T * S,

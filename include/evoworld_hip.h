@@ -27,7 +27,7 @@ typedef int ew_status;
 #define EW_ERR_UNSUPPORTED (-2)
 #define EW_ERR_HIP (-3)
 
-#define EW_ABI_VERSION 5
+#define EW_ABI_VERSION 6
 int ew_abi_version(void);
 const char* ew_last_error(void);
 
@@ -191,6 +191,14 @@ ew_status ew_layernorm_f16(const void* x, const void* x_lo, const void* addvec, 
  * (SURVEY.md §8a U10). */
 ew_status ew_attn_spatial_f16(const void* q, const void* k, const void* vt, void* o, int n_seq, int S, int heads,
                               int ld_qk, long long ld_vt, int ld_o, float scale, void* stream);
+
+/* Same core for q and k that arrive PRE-SCALED (ABI 6): the projection GEMM's epilogue multiplied both by sqrt(scale * log2 e)
+ * (ew_gemm_args.c_acc, applied in fp32 before the single rounding to fp16, so q and k carry the same relative rounding error as
+ * unscaled ones), which makes q.k the softmax exponent in log2 units.  The kernel then lets the MFMA subtract the running maximum
+ * (C operand = -m) and drops the per-score multiply-add: o = softmax_2(q k^T) v.  Same layouts and restrictions as above.
+ * Replaces the same F.scaled_dot_product_attention call. */
+ew_status ew_attn_spatial_log2_f16(const void* q, const void* k, const void* vt, void* o, int n_seq, int S, int heads,
+                                   int ld_qk, long long ld_vt, int ld_o, void* stream);
 
 /* Temporal self-attention core over the frame axis (T <= 64, head_dim 64; T <= 32 runs the one-block kernel) on frame-major tokens
  * [B, T, S, *]: sequence (b, s) attends over t -- the [B*T,S,C] <-> [B*S,T,C] regroup of

@@ -265,6 +265,34 @@ def test_attn_spatial(ops, n_seq, S, heads):
     assert rel_l2(o.float().cpu(), ref.cpu()) < 2e-3
 
 
+@pytest.mark.parametrize("n_seq,S,heads,shift", [(2, 512, 2, 0.0), (1, 1000, 1, 0.0), (3, 136, 5, 0.0), (1, 2304, 1, -60.0), (1, 640, 2, 40.0)])
+def test_attn_spatial_log2(ops, n_seq, S, heads, shift):
+    """ew_attn_spatial_log2_f16: q, k pre-scaled by sqrt(scale * log2 e) (what the projection epilogue writes); the MFMA's C operand
+    subtracts the running max.  `shift` moves every score of a head by a constant (one extra q / k channel pair): strongly negative
+    first-tile maxima (the max must be SET on the first tile, not only raised) and large positive ones (deferred-max raises)."""
+    C = heads * 64
+    rows = n_seq * S
+    qk32 = rnd(rows, 2 * C, seed=1)
+    v = rnd(rows, C, seed=2).half().to(DEV)
+    qk32[: S // 2, :64] *= 4.0                     # sharpen some rows so the running max moves between tiles
+    if shift:
+        qk32[:, 0] = abs(shift) ** 0.5 * 8 ** 0.5  # q_0 * k_0 * scale = shift
+        qk32[:, C] = (1 if shift > 0 else -1) * abs(shift) ** 0.5 * 8 ** 0.5
+        qk32[S // 3:, C] *= 0.5                    # ... and smaller for later keys: the first tile holds the max
+    qk = (qk32 * ops.QK_LOG2_PRESCALE).half().to(DEV)
+    vt = v.T.contiguous()
+    o = torch.empty(rows, C, dtype=torch.float16, device=DEV)
+    ops.attn_spatial_log2(qk, qk[:, C:], vt, o, n_seq, S, heads, 2 * C, rows, C)
+    q = qk[:, :C].float().reshape(n_seq, S, heads, 64).transpose(1, 2)
+    k = qk[:, C:].float().reshape(n_seq, S, heads, 64).transpose(1, 2)
+    vv = v.float().reshape(n_seq, S, heads, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(q, k, vv, scale=math.log(2.0)).transpose(1, 2).reshape(rows, C)   # 2^(q.k) = e^(ln2 q.k)
+    assert torch.isfinite(o).all()
+    e = rel_l2(o.float().cpu(), ref.cpu())
+    print(f"attn_spatial_log2 n_seq={n_seq} S={S} heads={heads} shift={shift}: rel-L2 {e:.2e}")
+    assert e < 2e-3
+
+
 @pytest.mark.parametrize("B,T,S,heads", [(2, 25, 37, 2), (1, 4, 512, 1), (2, 1, 9, 3), (1, 32, 5, 1), (2, 49, 21, 2), (1, 64, 7, 1),
                                          (1, 33, 130, 3)])
 def test_attn_temporal(ops, B, T, S, heads):

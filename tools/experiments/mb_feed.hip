@@ -139,6 +139,67 @@ __global__ __launch_bounds__(512, 2) void gemm_like_kernel(const char* __restric
     if (ktiles == -1) sink[tid] = smem[tid];
 }
 
+
+// ---- Round 4: the same GEMM-like feed with the A operand stored CHUNK-MAJOR, [K/64][M][64]: a 256-row K-tile is
+// one contiguous 32 KB run (each wave instruction 1 KB contiguous) instead of 256 pieces of 128 B at pitch S.  SHARE = number of
+// blocks of one XCD that read the same A rows (1: N = 320, A streamed once from HBM; 4: N = 1280, four tile columns in phase).
+// WORK = dependent-FMA filler per K-tile (0: pure feed; ~1.9 us: the MFMA time of a 256x320x64 tile at 1400 TF/s), so the second
+// regime measures whether the tile ARRIVES within one compute interval (latency), not the peak stream rate.
+template <int LAYOUT, int SHARE, int INFLIGHT>
+__global__ __launch_bounds__(512, 2) void gemm_like2_kernel(const char* __restrict__ wsrc, const char* __restrict__ asrc, int S,
+                                                            int nk, int ktiles, int work, size_t mtot, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int srow = lane >> 3, slot = (lane & 7) ^ srow;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;              // 32 blocks per XCD
+    const size_t mblk = (size_t)(xcd * (32 / SHARE) + idx / SHARE);     // A row block owned (shared by SHARE blocks of the XCD)
+    int kt = (int)((mblk * 7) % nk);
+    float f = (float)tid;
+    for (int v = 0; v < ktiles; ++v) {
+        char* buf = smem + (v & 1) * 73728;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave + 8 * i) * 8 + srow;
+            const char* src = LAYOUT == 0 ? asrc + (mblk * 256 + row) * (size_t)S + kt * 128 + slot * 16
+                                          : asrc + ((size_t)kt * mtot + mblk * 256 + row) * 128 + slot * 16;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + (wave + 8 * i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int row = (wave + 8 * j) * 8 + srow;
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)row * S + kt * 128 + slot * 16), (lptr_t)(buf + 32768 + (wave + 8 * j) * 1024), 16, 0, 0);
+        }
+        for (int w = 0; w < work; ++w) f = __builtin_fmaf(f, 1.0000001f, 0.5f);      // 4-clock dependent chain per iteration
+        if constexpr (INFLIGHT == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (++kt == nk) kt = 0;
+    }
+    if (ktiles == -1 || f == 12345.678f) sink[tid] = smem[tid] + f;
+}
+
+template <int LAYOUT, int SHARE, int INFLIGHT>
+void run_gemm_like2(const char* wsrc, const char* asrc, int S, int work, float* sink) {
+    const int ktiles = 4000, nk = S / 128;
+    const size_t lds = 2 * 73728;
+    const size_t mtot = (size_t)256 * 256 / SHARE;
+    CK(hipFuncSetAttribute((const void*)gemm_like2_kernel<LAYOUT, SHARE, INFLIGHT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((gemm_like2_kernel<LAYOUT, SHARE, INFLIGHT>), dim3(256), dim3(512), lds, 0, wsrc, asrc, S, nk, ktiles, work, mtot, sink);
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, a, b));
+        if (rep == 2) printf("r4 S=%5d A %-11s share %d in-flight %d work %4d: %8.3f ms  %6.1f GB/s per CU staged, A from memory %5.2f TB/s, %6.3f us per K-tile\n", S,
+                        LAYOUT ? "chunk-major" : "row-major", SHARE, INFLIGHT, work, ms, 73728.0 * ktiles / ms / 1e6,
+                        32768.0 * ktiles * (256 / SHARE) / ms / 1e9, ms * 1e3 / ktiles);
+    }
+}
+
 template <bool ALIAS_A, int INFLIGHT>
 void run_gemm_like(const char* wsrc, const char* asrc, int S, float* sink, const char* label) {
     const int ktiles = 4000, nk = S / 128;
@@ -202,6 +263,20 @@ int main() {
         run_gemm_like<true, 2>(w, a, S, sink, "W 320 rows shared, A one line");
         run_gemm_like<false, 1>(w, a, S, sink, "W shared, A 256 private rows per block");
         run_gemm_like<false, 2>(w, a, S, sink, "W shared, A 256 private rows per block");
+    }
+    // round 4: row-major vs chunk-major A.  work: 0 = pure feed; the filler loop costs ~14.5 ns per iteration (measured: 420 -> 6.2 us per
+    // K-tile), so 60 / 120 / 180 = ~0.9 / 1.8 / 2.6 us of compute per K-tile (a 256x320x64 tile is ~1.9 us of MFMA time at 1400 TF/s)
+    for (int S : {1280, 2560, 5120, 10240}) {
+        const char* w = big;
+        const char* a = big + (size_t)320 * 10496;
+        for (int work : {0, 60, 120, 180}) {
+            run_gemm_like2<0, 1, 1>(w, a, S, work, sink);
+            run_gemm_like2<1, 1, 1>(w, a, S, work, sink);
+            run_gemm_like2<0, 4, 1>(w, a, S, work, sink);
+            run_gemm_like2<1, 4, 1>(w, a, S, work, sink);
+        }
+        run_gemm_like2<0, 1, 2>(w, a, S, 0, sink);
+        run_gemm_like2<1, 1, 2>(w, a, S, 0, sink);
     }
     return 0;
 }
