@@ -10,7 +10,12 @@
 // Why a fused kernel: as LayerNorm + two GEMMs the 1280-wide GEGLU intermediate of level 0 (460800 x 1280 fp16 = 1.18 GB) is
 // written and read back 15 times per forward and the normalised tensor 15 times more.  Here neither leaves the chip:
 //   * one workgroup = 8 waves as 4 (M) x 2 (N), two per SIMD, on a 128-row tile.  A wave owns 32 rows; their (normalised) x
-//     fragments stay in 80 registers for the whole tile.  The LayerNorm runs on those registers (prologue);
+//     fragments stay in 80 registers for the whole tile.  The LayerNorm runs on those registers (prologue).  Register
+//     budget as compiled (-Rpass-analysis=kernel-resource-usage, round 4): 256 VGPRs, 0 AGPRs, 197-224 spilled VGPRs
+//     (792-864 B of scratch per lane; ~400 with the LayerNorm prologue) -- every scratch access sits in the per-TILE
+//     prologue / epilogue (x-fragment load, direct epilogue: 174 + 11 scratch instructions per tile against 2400 MFMAs);
+//     the 40-iteration chunk loop itself holds x fragments, both accumulator sets and the W fragments in registers with
+//     zero scratch traffic (checked in the ISA: no scratch_load / scratch_store between the loop header and its back edge);
 //   * the hidden dimension is walked in 40 chunks of 32.  Up-projection of a chunk: the wave computes the value + gate columns
 //     of ITS half of the chunk (16 hidden units: 2 fragments x 2 row fragments x 10 k-steps = 40 MFMAs), applies bias and
 //     value * gelu(gate) in registers and leaves its four halves per lane in a small LDS exchange buffer; after the chunk's
@@ -135,7 +140,8 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
     };
     issue_w1(0, 0);
     int cc = 0;                                 // global chunk index
-    __syncthreads();                            // b1 staged; W1(0) landed (the barrier's fence drains the DMA queue)
+    FF_WAIT_VM0_LGKM0();                        // every wave drains ITS OWN DMA pieces of W1(0) (vmcnt) and its LDS writes before the
+    __syncthreads();                            // barrier: the fragment reads below cover pieces other waves loaded (b1 staged too)
     if (CC_total > 1) issue_w1(1, 1);
 
     // fragment read offsets.  W1 K-tile image: staged row R = j*16 + frow (128-byte rows), 16-byte k-slot ks in 0..7 ->

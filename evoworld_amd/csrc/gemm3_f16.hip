@@ -733,7 +733,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
 struct SkWorkspace { int dev; hipStream_t stream; float* ws; unsigned* flags; unsigned epoch; };
 constexpr int SK_SLOTS = 256;
 constexpr size_t SK_SLOT_FLOATS = (size_t)FM * FN * 4 * 64 * NW;          // 160 accumulators x 512 threads = 320 KB
-static SkWorkspace sk_pool[8];
+constexpr int SK_POOL = 64;                                                  // (device, stream) pairs of the whole process
+static SkWorkspace sk_pool[SK_POOL];
 static int sk_pool_used = 0;
 SkWorkspace* sk_pool_entry(int i) { return i < sk_pool_used ? &sk_pool[i] : nullptr; }
 static std::mutex sk_mutex;                                                   // the pool is shared by every host thread
@@ -747,7 +748,7 @@ SkWorkspace* sk_workspace(hipStream_t stream, bool create) {
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     for (int i = 0; i < used; ++i)
         if (pool[i].dev == dev && pool[i].stream == stream) return &pool[i];
-    if (!create || used == 8) return nullptr;                               // more streams than slots: those launches run without the tail split
+    if (!create || used == SK_POOL) return nullptr;                         // pool full: those launches run the whole-tile schedule
     SkWorkspace w{dev, stream, nullptr, nullptr, 0};
     // uncached (MTYPE UC) device memory: partials and flags cross XCDs inside one kernel, and the per-XCD L2s are only coherent
     // at kernel boundaries for ordinary allocations
@@ -773,7 +774,7 @@ int ew_gemm3_sk_init_b256(hipStream_t s);
 extern "C" ew_status ew_gemm_streamk_init(void* stream) {
     const bool a = sk_workspace((hipStream_t)stream, true) != nullptr;
     const bool b = ew_gemm3_sk_init_b256((hipStream_t)stream) != 0;
-    if (!a || !b) { ew_set_error("ew_gemm_streamk_init: workspace allocation failed (or more than 8 streams per device)"); return EW_ERR_HIP; }
+    if (!a || !b) { ew_set_error("ew_gemm_streamk_init: no stream-K workspace for this (device, stream): allocation failed or all 64 process-wide pool entries are in use; launches on it run the whole-tile schedule"); return EW_ERR_HIP; }
     return EW_OK;
 }
 extern "C" int ew_gemm_streamk_status(void) {
@@ -785,7 +786,7 @@ int ew_gemm3_sk_init_b256(hipStream_t s) { return sk_workspace(s, true) != nullp
 int ew_gemm3_sk_status_b256() {
     int bad = 0;
 #endif
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < SK_POOL; ++i) {
         SkWorkspace* w = sk_pool_entry(i);
         if (!w) break;
         unsigned word = 0;

@@ -197,7 +197,7 @@ class UnifiedLoopConsistencyPipeline:
             gens = self.nav.navigate_curve_path(cam_t, first, num_inference_steps=self.steps, memorized_images=memory[None],
                                                 infer_segment=True, segment_id=seg, output_type="latent", **cond, **pipe_kw)
             latents, _n = gens[-1]
-            if image_latents_fn is None and self.frames_from_latents is None:
+            if self.frames_from_latents is None:                                          # the pipeline's own VAE decodes (chunks of 8)
                 pipe = self.nav.pipe
                 dec = pipe.decode_latents(latents, self.num_frames, 8)[0].permute(1, 0, 2, 3)      # [T,3,H,W] in [-1,1]
             else:

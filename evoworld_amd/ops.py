@@ -119,12 +119,24 @@ _sk_ready = set()
 
 
 def streamk_init():
-    """Allocate generation 3's stream-K workspace for (current device, current stream) once, outside any kernel launch path
-    (ew_gemm_streamk_init; needed before capturing launches into a hipGraph)."""
+    """Best effort: allocate generation 3's stream-K workspace for (current device, current stream) once, outside any kernel
+    launch path (ew_gemm_streamk_init).  Nothing depends on it succeeding -- a launch without a workspace runs the whole-tile
+    schedule -- so a full pool (64 (device, stream) pairs per process) or a failed allocation only warns.  Skipped when the
+    tail split cannot be used (EW_GEMM_GEN != 3, EW_G3_SK=0) and while the current stream is being captured into a graph
+    (allocation + memset are illegal there; call it on the capture stream BEFORE the capture to get the tail inside the graph)."""
+    import os
     key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
-    if key not in _sk_ready:
-        _lib.check(_lib.load().ew_gemm_streamk_init(_stream()), "ew_gemm_streamk_init")
-        _sk_ready.add(key)
+    if key in _sk_ready:
+        return
+    if _lib.load().ew_get_gemm_generation() != 3 or os.environ.get("EW_G3_SK", "1") == "0":
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return
+    _sk_ready.add(key)
+    if _lib.load().ew_gemm_streamk_init(_stream()) != 0:
+        import warnings
+        msg = _lib.load().ew_last_error()
+        warnings.warn("ew_gemm_streamk_init: " + (msg.decode() if msg else "failed") + " (continuing without the stream-K tail on this stream)")
 
 
 def streamk_check():

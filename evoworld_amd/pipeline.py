@@ -27,6 +27,7 @@ from .unet import CPAD_IN
 
 
 _RANDN_CACHE = {}
+_RANDN_CACHE_BYTES = 512 << 20          # device bytes the memoised draws may hold (two full-size windows' worth)
 
 
 def _randn_like_reference(shape, generator, device, dtype=torch.float32):
@@ -35,7 +36,7 @@ def _randn_like_reference(shape, generator, device, dtype=torch.float32):
     the 46 M-value augmentation noise and the latents are the same tensors window after window: draws are memoised on
     (generator state, shape, dtype) -- a hit restores the generator to the state the real draw would have left it in and returns
     the device-resident tensor (0.35 s of host RNG + 184 MB of PCIe per window at 576x1024x25 otherwise).  Bit-identical to
-    drawing again by construction; the returned tensor must not be modified in place."""
+    drawing again by construction; a clone is returned (a 184 MB device copy is ~50 us)."""
     if not isinstance(generator, torch.Generator):
         return torch.randn(shape, generator=generator, device=device, dtype=dtype)
     if generator.device.type != "cpu":
@@ -44,12 +45,17 @@ def _randn_like_reference(shape, generator, device, dtype=torch.float32):
     hit = _RANDN_CACHE.get(key)
     if hit is not None:
         generator.set_state(hit[1])
-        return hit[0]
+        return hit[0].clone()              # callers may modify what they get; the memoised tensor stays pristine
     t = torch.randn(shape, generator=generator, device="cpu", dtype=dtype).to(device)
-    if len(_RANDN_CACHE) >= 4:
-        _RANDN_CACHE.pop(next(iter(_RANDN_CACHE)))
     _RANDN_CACHE[key] = (t, generator.get_state().clone())
-    return t
+    while len(_RANDN_CACHE) > 1 and sum(v[0].numel() * v[0].element_size() for v in _RANDN_CACHE.values()) > _RANDN_CACHE_BYTES:
+        _RANDN_CACHE.pop(next(iter(_RANDN_CACHE)))            # oldest first
+    return t.clone()
+
+
+def clear_randn_cache():
+    """Drop the memoised reference-noise tensors (device memory: 184 MB for the augmentation noise of a 576x1024x25 window)."""
+    _RANDN_CACHE.clear()
 
 
 def _append_dims(x, target_dims):
@@ -259,10 +265,10 @@ class StableVideoDiffusionPipeline:
             noise = image_noise if image_noise is not None else _randn_like_reference(flat.shape, generator, dev, flat.dtype)
             flat = flat + noise_aug_strength * noise.to(dev)                                 # :599-600
             image_latents = self.vae.encode(flat).latent_dist.mode().reshape(1, -1, 4, height // 8, width // 8)
-        elif image_noise is None and isinstance(generator, torch.Generator) and memorized_pixel_values is not None:
-            # injected conditioning: keep the reference's RNG order anyway -- the [1+T,3,H,W] augmentation-noise draw comes
-            # first (:596-600), so the latents below are the generator's SECOND draw, as in the reference
-            _randn_like_reference((1 + memorized_pixel_values.shape[1],) + tuple(image.shape[1:]), generator, dev)
+        elif image_noise is None and isinstance(generator, torch.Generator):
+            # injected conditioning: keep the reference's RNG order anyway -- the [n_cond,3,height,width] augmentation-noise draw
+            # (shape after VideoProcessor.preprocess, :594-599) comes first, so the latents below are the generator's SECOND draw
+            _randn_like_reference((image_latents.shape[1], 3, height, width), generator, dev)
         image_latents = image_latents.to(device=dev, dtype=torch.float32).clone()
         image_embeddings = image_embeddings.to(device=dev, dtype=torch.float32)
         if image_latents.shape[1] != num_frames + 1:

@@ -112,7 +112,7 @@ class HipStages(SyntheticStages):
         x = torch.cat([first[None], memory], 0)                                         # [-1,1]
         emb = self.clip(encode_image_preprocess(x[:1] / 2 + 0.5)).image_embeds[:, None]
         if image_noise is None:
-            image_noise = torch.randn(x.shape, generator=torch.manual_seed(-1))
+            image_noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(-1))   # private: the global RNG is not touched
         lat = self.vae.encode(x + self.noise_aug_strength * image_noise.to(x.device)).latent_dist.mode()
         return dict(image_latents=lat[None], image_embeddings=emb)
 

@@ -117,7 +117,9 @@ def test_window_rng_draws_are_memoised_bit_exactly():
     tail2 = torch.randn(4, generator=g)
     ref = torch.manual_seed(-1)
     want_a, want_b, want_t = torch.randn((2, 3, 5), generator=ref), torch.randn((1, 7), generator=ref), torch.randn(4, generator=ref)
-    assert a2 is a1 and b2 is b1 and len(_RANDN_CACHE) == 2
+    assert torch.equal(a2, a1) and torch.equal(b2, b1) and len(_RANDN_CACHE) == 2
+    a2.zero_()                                                  # callers own what they get: the memoised tensor is not aliased
+    assert torch.equal(_randn_like_reference((2, 3, 5), torch.manual_seed(-1), "cpu"), want_a)
     assert torch.equal(a1, want_a) and torch.equal(b1, want_b) and torch.equal(tail1, want_t) and torch.equal(tail2, want_t)
     g = torch.manual_seed(7)                                    # another seed: no false hit
     assert not torch.equal(_randn_like_reference((2, 3, 5), g, "cpu"), a1)

@@ -46,32 +46,7 @@ class _FakeCLIP:
         return type("O", (), {"image_embeds": v})
 
 
-def _oracle_loop(ref, lat0, il, ehs, pl, T, steps, mask_mem=False, trace=None, start=0, lat_start=None, stop_after=None, on_step=None):
-    """fp32 CPU oracle of the denoise loop.  start / lat_start resume it from the latents after step `start` (a checkpoint of an
-    earlier call: the full-size 25-step run is longer than one gpurun call), stop_after ends it early, on_step(i, lat) is called after
-    every step (checkpoint writer)."""
-    from evoworld_amd.scheduler import EulerDiscreteScheduler
-    from oracle.reproject_ref import euler_cfg_step_ref
-    s = EulerDiscreteScheduler()
-    s.set_timesteps(steps)
-    lat = lat0 * s.init_noise_sigma if lat_start is None else lat_start
-    il2 = torch.cat([torch.zeros_like(il), il])
-    if mask_mem:
-        il2[:, 1:] = 0
-    cond = torch.cat([il2[:, 0:1].repeat(1, T, 1, 1, 1), il2[:, 1:], torch.cat([pl, pl])], dim=2)
-    e2 = torch.cat([torch.zeros_like(ehs), ehs])
-    ids = torch.tensor([[6.0, 127.0, 0.02]] * 2)
-    guid = torch.linspace(1.0, 3.0, T)
-    for i in range(start, steps if stop_after is None else min(steps, stop_after)):
-        sig, sign = float(s.sigmas[i]), float(s.sigmas[i + 1])
-        x = torch.cat([torch.cat([lat, lat]) / (sig ** 2 + 1) ** 0.5, cond], dim=2)
-        eps = ref(x, s.timesteps[i], e2, ids)
-        lat = euler_cfg_step_ref(eps[0:1], eps[1:2], lat, guid, sig, sign)
-        if trace is not None:
-            trace.append(lat.clone())
-        if on_step is not None:
-            on_step(i, lat)
-    return lat
+from oracle.pipeline_ref import oracle_loop as _oracle_loop  # noqa: E402  (pinned by tests/test_cpu_pipeline_glue.py)
 
 
 @pytest.fixture(scope="module")

@@ -8,6 +8,11 @@ bottleneck (mid / up0: 1.17e-3 tiny, 1.01e-3 full size) and falls again towards 
 (a 20 % regression of the worst tap fails)."""
 TOL_FORWARD = 1.0e-3
 TOL_TAP = 1.5e-3
+# SURVEY §8d weight protocol (oracle keeps fp32 weights, HIP packs them to fp16): rounding 1.5 G weights to fp16 is one more
+# operand-rounding term of the same size as the activations' -- the fp16-operand floor of ONE forward rises from 7.5e-4 to
+# 1.05e-3 (tests/analysis_fp16_floor.py main(): "(a) fp16 operands only"), so one forward of an fp32 checkpoint cannot meet
+# 1e-3 on fp16 MFMA operands; the 25-step clip does (tests/test_gpu_pipeline_glue.py).  Asserted at 1.25 x that floor.
+TOL_FORWARD_FP32_WEIGHTS = 1.3e-3
 import pytest
 import torch
 
@@ -16,13 +21,18 @@ from conftest import rel_l2
 pytestmark = pytest.mark.gpu
 
 
-def _setup(cfg, B, T, h, w, seed=0):
-    from evoworld_amd.unet import UNetSpatioTemporalConditionModel, random_state_dict
+def _setup(cfg, B, T, h, w, seed=0, fp16_representable_weights=True):
+    """fp16_representable_weights=True: the random checkpoint is rounded to fp16 FIRST and loaded into both models (what a
+    `variant="fp16"` checkpoint is) -- the assumption behind the 1e-3-per-forward figures.  False = SURVEY §8d's protocol: the oracle
+    keeps the un-rounded fp32 weights (the reference runs weight_dtype=float32, unified_loop_consistency.py:188), the HIP loader
+    packs the same fp32 dict to fp16."""
+    from evoworld_amd.unet import DEFAULT_CONFIG, UNetSpatioTemporalConditionModel, random_state_dict
     from oracle.unet_ref import UNetSpatioTemporalConditionModelRef
-    full = dict(cfg)
-    sd = {k: v.half().float() for k, v in random_state_dict({**__import__("evoworld_amd.unet", fromlist=["DEFAULT_CONFIG"]).DEFAULT_CONFIG, **full}, seed).items()}
+    sd = random_state_dict({**DEFAULT_CONFIG, **cfg}, seed)
+    if fp16_representable_weights:
+        sd = {k: v.half().float() for k, v in sd.items()}
     ref = UNetSpatioTemporalConditionModelRef(**cfg).eval()
-    missing, unexpected = ref.load_state_dict(sd, strict=True), None
+    ref.load_state_dict(sd, strict=True)
     m = UNetSpatioTemporalConditionModel(**cfg).load_state_dict(sd, device="cuda")
     g = torch.Generator().manual_seed(seed + 1)
     x = torch.randn(B, T, cfg["in_channels"], h, w, generator=g)
@@ -52,6 +62,20 @@ def test_unet_tiny_vs_oracle():
     print(f"unet tiny forward rel-L2 {e:.3e}")
     assert torch.isfinite(got).all()
     assert worst < TOL_TAP and e < TOL_FORWARD
+
+
+def test_unet_tiny_vs_oracle_fp32_weights():
+    """SURVEY §8d protocol: un-rounded fp32 weights in the oracle, the same dict packed to fp16 by the HIP loader."""
+    from oracle.unet_ref import tiny_config
+    cfg = tiny_config()
+    B, T, h, w = 2, 4, 16, 32
+    out = []
+    for rep in (True, False):
+        m, ref, x, ehs, ids = _setup(cfg, B, T, h, w, fp16_representable_weights=rep)
+        t = torch.tensor(1.6377)
+        out.append(rel_l2(m(x.cuda(), t, ehs.cuda(), ids.cuda(), return_dict=False)[0].cpu(), ref(x, t, ehs, ids)))
+    print(f"unet tiny forward rel-L2: fp16-representable checkpoint {out[0]:.3e} | fp32 checkpoint (SURVEY 8d protocol) {out[1]:.3e}")
+    assert out[0] < TOL_FORWARD and out[1] < TOL_FORWARD_FP32_WEIGHTS
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
@@ -127,7 +151,9 @@ def test_unet_full_size_forward_vs_oracle():
                num_attention_heads=(5, 10, 20, 20), num_frames=25)           # evoworld/trainer/unet_plucker.py:69-94, in_channels 18
     B, T, h, w = 2, 25, 72, 128
     torch.set_num_threads(min(int(__import__("os").environ.get("EW_ORACLE_THREADS", "32")), __import__("os").cpu_count() or 1))
-    m, ref, x, ehs, ids = _setup(cfg, B, T, h, w, seed=7)
+    # EW_FULL_FP32_WEIGHTS=1: the same test under SURVEY §8d's weight protocol (builder-run; result under profiles/)
+    fp32w = __import__("os").environ.get("EW_FULL_FP32_WEIGHTS") == "1"
+    m, ref, x, ehs, ids = _setup(cfg, B, T, h, w, seed=7, fp16_representable_weights=not fp32w)
     t = torch.tensor(1.6377)
     gt = {}
     got = m(x.cuda(), t, ehs.cuda(), ids.cuda(), return_dict=False, taps=gt)[0]
@@ -146,6 +172,6 @@ def test_unet_full_size_forward_vs_oracle():
         print(f"full-size tap {k:8s} rel-L2 {e:.2e}")
         worst = max(worst, e)
     e = rel_l2(got.cpu(), want)
-    print(f"unet FULL-SIZE forward (B=2, T=25, 72x128 latents, 1.52 B parameters) rel-L2 {e:.3e}")
+    print(f"unet FULL-SIZE forward (B=2, T=25, 72x128 latents, 1.52 B parameters, {'fp32 checkpoint' if fp32w else 'fp16-representable checkpoint'}) rel-L2 {e:.3e}")
     assert torch.isfinite(got).all()
-    assert worst < TOL_TAP and e < TOL_FORWARD
+    assert worst < (1.8e-3 if fp32w else TOL_TAP) and e < (TOL_FORWARD_FP32_WEIGHTS if fp32w else TOL_FORWARD)
