@@ -124,10 +124,11 @@ def kernel_breakdown(unet, pipe, latents, image_latents, ehs, plucker, T, h, w, 
     lib = _lib.load()
     rec = []
     names = ("ew_gemm_f16", "ew_groupnorm_stats_f16", "ew_groupnorm_finalize", "ew_groupnorm_apply_f16", "ew_layernorm_f16",
-             "ew_attn_spatial_f16", "ew_attn_temporal_f16")
+             "ew_attn_spatial_f16", "ew_attn_spatial_log2_f16", "ew_attn_temporal_f16", "ew_ff_geglu320_f16")
     kname = {"ew_groupnorm_stats_f16": "gn_stats_kernel", "ew_groupnorm_finalize": "gn_finalize_kernel",
              "ew_groupnorm_apply_f16": "gn_apply_kernel",
-             "ew_layernorm_f16": "ln_kernel", "ew_attn_spatial_f16": "attn_spatial_kernel", "ew_attn_temporal_f16": "attn_temporal_kernel"}
+             "ew_layernorm_f16": "ln_kernel", "ew_attn_spatial_f16": "attn_spatial_kernel", "ew_attn_spatial_log2_f16": "attn_spatial_kernel",
+             "ew_attn_temporal_f16": "attn_temporal_kernel", "ew_ff_geglu320_f16": "ff320_kernel"}
     orig = {n: getattr(lib, n) for n in names}
 
     def wrap(n):
@@ -152,10 +153,13 @@ def kernel_breakdown(unet, pipe, latents, image_latents, ehs, plucker, T, h, w, 
                         key += f" rows={a[9]} C={a[10]}"
                     elif n.startswith("ew_groupnorm") and n != "ew_groupnorm_finalize":
                         key += f" slabs={a[-9] if n.endswith('apply_f16') else a[3]}"
-                    elif n == "ew_attn_spatial_f16":
+                    elif n.startswith("ew_attn_spatial"):
                         key += f" S={a[5]}"
-                if n == "ew_attn_spatial_f16":
+                if n.startswith("ew_attn_spatial"):
                     fl = 4.0 * a[4] * a[6] * a[5] * a[5] * 64          # n_seq * heads * S^2 * head_dim
+                elif n == "ew_ff_geglu320_f16":
+                    g = a[0]._obj
+                    fl = 2.0 * g.M * g.C * 2 * g.hidden + 2.0 * g.M * g.hidden * g.C   # up-projection (value + gate) + down-projection
             rec.append((key, fl, s, e))
             return r
         return timed
@@ -229,6 +233,10 @@ def main():
     ap.add_argument("--no-fp16-stream", action="store_true", help="skip the extra fp16-stream forwards (profiling runs: keeps the launch count at steps x denoise-steps + 1)")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="time ONE complete full-size CPU forward (minutes) instead of the bounded sample")
     ap.add_argument("--tiny", action="store_true", help="shrunken U-Net (plumbing check only; result flagged invalid)")
+    ap.add_argument("--split", choices=["clip", "cfg"], default=os.environ.get("EW_BENCH_SPLIT", "clip"),
+                    help="multi-GPU axis: clip = one independent clip per rank (weak scaling, default); cfg = ranks 2p, 2p+1 share clip p, "
+                         "one CFG row each with one all_gather of eps per denoise step (strong scaling per clip; --gpus 1: both rows as "
+                         "two B=1 forwards on the one rank)")
     args = ap.parse_args()
 
     # --gpus N from a plain `python bench.py`: re-exec as N ranks (one process per GPU) under torch.distributed.run
@@ -286,7 +294,16 @@ def main():
             print(f"[bench] weight broadcast to {world} rank(s): {t_b * 1e3:.1f} ms, checksum {cs:.6e} on every rank", file=sys.stderr)
     pipe = StableVideoDiffusionPipeline(unet=unet, scheduler=EulerDiscreteScheduler())
     T, h, w = args.frames, args.height // 8, args.width // 8
-    latents, image_latents, ehs, plucker = synth_inputs(T, h, w, seed=10 + rank, device=dev)
+    n_clips = world                                  # clips in flight per "step" over the whole job
+    if args.split == "cfg":
+        if world > 1 and world % 2:
+            raise SystemExit(f"--split cfg needs an even rank count (got {world})")
+        grp = D.CfgGroup(rank, world, size=2 if world > 1 else 1)
+        pipe.cfg_group = grp
+        n_clips = grp.n_pairs
+        latents, image_latents, ehs, plucker = synth_inputs(T, h, w, seed=10 + grp.pair, device=dev)   # both members: the same clip
+    else:
+        latents, image_latents, ehs, plucker = synth_inputs(T, h, w, seed=10 + rank, device=dev)
     dummy_image = torch.zeros(1, 3, args.height, args.width, device=dev)
 
     def one_clip():
@@ -330,22 +347,27 @@ def main():
     if rank == 0:
         fw_ms = sum(s.elapsed_time(e) for s, e in fw_events) / max(1, len(fw_events))
         full = (not args.tiny) and (T, args.height, args.width, args.denoise_steps) == (25, 576, 1024, 25)
-        ach = ALGO_TFLOP_PER_FORWARD / (fw_ms / 1e3) if full else None
+        algo = ALGO_TFLOP_PER_FORWARD / (2 if args.split == "cfg" else 1)     # cfg split: a forward is ONE CFG row (B = 1)
+        ach = algo / (fw_ms / 1e3) if full else None
         tr = committed_traffic("split" if unet.split_residual else "fp16")
         line = {
             "metric": "panoramic frames/sec per clip (576x1024x25f, 25 denoise steps)",
-            "value": world * T * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": n_clips * T * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if (args.split == "cfg" and world == 2) else "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"configs[1]: single clip {args.height}x{args.width}x{T}f, {args.denoise_steps} EulerDiscrete "
-                                   "steps, CFG batch 2, random-init SVD-Xtend U-Net (in_channels 18), one clip per GPU",
+                                   "steps, CFG batch 2, random-init SVD-Xtend U-Net (in_channels 18), "
+                                   + ("one clip per GPU" if args.split == "clip" else
+                                      f"CFG-pair split: {n_clips} clip(s) over {world} rank(s), one CFG row per rank, all_gather of eps per step"),
+                       "parallelism": (f"dp{world}" if args.split == "clip" else f"cfg{min(2, world)} x dp{n_clips}"),
                        "unet_forward_ms": fw_ms, "residual_stream": "split fp16 + int8 (3 B/elt)" if unet.split_residual else "fp16",
                        "unet_forward_ms_fp16_stream": fp16_ms, "valid": bool(full and finite)},
             "roofline": {"bound": "mfma", "kernel": "U-Net denoise step (all launches of one forward, HIP events on the launch stream)",
                          "achieved": ach, "peak": PEAK_F16_DENSE_TFLOPS, "unit": "TFLOP/s",
                          "frac": (ach / PEAK_F16_DENSE_TFLOPS) if ach else None,
                          "traffic": (tr or {}).get("bytes_per_forward") if full and tr and not tr["stale"] else None, "traffic_detail": tr,
-                         "algorithmic_tflop_per_launch": ALGO_TFLOP_PER_FORWARD,
+                         "algorithmic_tflop_per_launch": algo,
                          "kernels": kernels},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -797,6 +797,21 @@ int ew_gemm3_sk_status_b256() {
 }
 namespace {
 
+// half split of small problems: see launch3.  EW_G3_SKHALF_MINK = smallest K it is used for (0 = off; A/B hook)
+inline int sk_half_min_k() {
+    static const int v = getenv("EW_G3_SKHALF_MINK") ? atoi(getenv("EW_G3_SKHALF_MINK")) : 2560;
+    return v;
+}
+inline bool sk_half_shape(const GemmP& p, long long tiles) {
+    static const int sk_mode = getenv("EW_G3_SK") ? atoi(getenv("EW_G3_SK")) : 1;
+    const int mk = sk_half_min_k();
+    return sk_mode && mk > 0 && !(p.dbg & 4) && tiles >= 8 && 2 * tiles <= 256 && (2 * tiles) % 8 == 0 && (p.K / BK) % 2 == 0 && p.K >= mk;
+}
+template <int MODE, int EPI>
+inline bool sk_half_applies(const GemmP& p, long long tiles) {
+    return !(MODE == EW_A_DENSE && EPI == 23) && sk_half_shape(p, tiles);
+}
+
 template <int MODE, int EPI>
 ew_status launch3(const GemmP& p, hipStream_t s) {
     GemmP q = p;
@@ -831,6 +846,21 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
                 sk.tiles = (int)(tiles - 256LL * sk.dp_rounds);
                 sk.ws = w->ws; sk.flags = w->flags; sk.epoch = sk_next_epoch(w);
             }
+        }
+    }
+    // Half split (round 4): problems with at most 128 tiles (the deepest level: M = 7200 -> 29 x 4 = 116 tiles) leave more than
+    // half of the 256 CUs idle on the whole-tile schedule and used to run on generation 2's 256x160 tiles.  With a long K every
+    // tile is cut into two K halves instead: 2 x tiles blocks, block 2t computes the head of tile t and finishes it with the
+    // partial of block 2t+1 (same contributor / finisher hand-over as the tail split: one range = exactly half a tile).
+    if (sk_half_applies<MODE, EPI>(p, tiles) && !sk.tiles) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        SkWorkspace* w = sk_workspace(s, cap == hipStreamCaptureStatusNone);
+        if (w) {
+            grid = (int)(2 * tiles);
+            sk.dp_rounds = 0;
+            sk.tiles = (int)tiles;
+            sk.ws = w->ws; sk.flags = w->flags; sk.epoch = sk_next_epoch(w);
         }
     }
     snprintf(g_gemm_last_kernel, 64, EW3_KERNEL_STR "<%d, %d>", MODE, EPI);
@@ -888,7 +918,10 @@ bool EW3_NAME(ew_gemm3_wants)(const GemmP& p) {
     static const int short_rule = getenv("EW_G3_SHORT") ? atoi(getenv("EW_G3_SHORT")) : 0;     // A/B hook: 1 = gen3 also there
     if (!short_rule && p.mode == EW_A_DENSE && p.N == BN && p.K <= 1280 && (p.r1 || p.r2)) return false;
     const long long tiles = (long long)ew_cdiv(p.M, BM) * (p.N / BN);
-    return tiles >= 200;
+    if (tiles >= 200) return true;
+    // fewer tiles than CUs: generation 3 only with the half split (launch3), i.e. not for the one variant compiled without it
+    const bool epi23 = p.mode == EW_A_DENSE && p.r2 && (p.r1_lo || p.r2_lo || p.out_lo);        // dispatch_epi3: <0, 16|7>
+    return !epi23 && p.act != EW_ACT_GEGLU && sk_half_shape(p, tiles);
 }
 
 ew_status EW3_NAME(ew_gemm3_dispatch)(const GemmP& p, hipStream_t s) {

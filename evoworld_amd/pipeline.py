@@ -77,6 +77,7 @@ class StableVideoDiffusionPipeline:
         self.vae_scale_factor = 8 if vae is None else 2 ** (len(vae.config.block_out_channels) - 1)
         self._device = unet.device or torch.device("cuda")
         self._progress = {}
+        self.cfg_group = None       # evoworld_amd.distributed.CfgGroup: split the two CFG rows of every step over a rank pair
 
     def set_components(self, vae=None, image_encoder=None, feature_extractor=None):
         """Plug in (or replace) the conditioning / decoding networks after construction: a stage provider of
@@ -200,7 +201,7 @@ class StableVideoDiffusionPipeline:
 
     # ------------------------------------------------------------------ the hot loop
     def denoise(self, latents, conditional_latents, image_embeddings, added_time_ids, guidance, num_inference_steps,
-                callback=None):
+                callback=None, cfg_group=None):
         """latents fp32 [1,T,4,h,w] (already scaled by init_noise_sigma); conditional_latents fp32 [2,T,14,h,w];
         image_embeddings [2,1,X]; added_time_ids [2,3]; guidance fp32 [T].  Returns final latents fp32 [1,T,4,h,w]."""
         dev = self._device
@@ -220,11 +221,29 @@ class StableVideoDiffusionPipeline:
         guidance = guidance.to(device=dev, dtype=torch.float32).contiguous()
         ehs = image_embeddings.to(dev)
         ids = added_time_ids.to(dev)
-        for i in range(num_inference_steps):
-            eps = self.unet.forward_nhwc(x_in, ts[i], ehs, ids, 2, T, h, w)
-            ops.euler_cfg_step(eps, eps.shape[-1], lat, guidance, float(sig[i]), float(sig[i + 1]), x_in, CPAD_IN, T, h, w)
-            if callback is not None:
-                callback(i, ts[i], lat)
+        grp = cfg_group if cfg_group is not None else self.cfg_group
+        if grp is None:
+            for i in range(num_inference_steps):
+                eps = self.unet.forward_nhwc(x_in, ts[i], ehs, ids, 2, T, h, w)
+                ops.euler_cfg_step(eps, eps.shape[-1], lat, guidance, float(sig[i]), float(sig[i + 1]), x_in, CPAD_IN, T, h, w)
+                if callback is not None:
+                    callback(i, ts[i], lat)
+        else:
+            # CFG-pair split (north_star "denoising-step batch"; the CFG batch of pipeline_evoworld.py:691-711): this rank runs
+            # the U-Net on its row(s) only (B = 1), ONE all_gather of the eps rows per step, combine + Euler step replicated --
+            # every member keeps the full latents and both rows of the next model input, so eps is all that crosses xGMI.
+            rows = T * h * w
+            eps_all = None
+            for i in range(num_inference_steps):
+                for r in grp.rows():
+                    eps_r = self.unet.forward_nhwc(x_in[r * rows:(r + 1) * rows], ts[i], ehs[r:r + 1], ids[r:r + 1], 1, T, h, w)
+                    if eps_all is None:
+                        eps_all = torch.zeros(2, rows, eps_r.shape[-1], dtype=eps_r.dtype, device=dev)
+                    eps_all[r].copy_(eps_r)
+                grp.all_gather_rows(eps_all, eps_r)       # eps_r: the forward's own output buffer (not a view of eps_all)
+                ops.euler_cfg_step(eps_all, eps_all.shape[-1], lat, guidance, float(sig[i]), float(sig[i + 1]), x_in, CPAD_IN, T, h, w)
+                if callback is not None:
+                    callback(i, ts[i], lat)
         ops.streamk_check()      # synchronises; raises if any stream-K hand-over of the loop timed out (wrong tile)
         return lat[None]
 

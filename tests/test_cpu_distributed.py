@@ -48,3 +48,72 @@ def test_single_process_helpers_are_noops():
     from evoworld_amd import distributed as D
     x = torch.ones(2)
     assert D.gather_results(x)[0] is x and D.shard_clips(3, 0, 1) == [0, 1, 2] and D.max_over_ranks(3.0, "cpu") == 3.0
+
+
+def _cfg_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from evoworld_amd import distributed as D
+    from oracle.reproject_ref import euler_cfg_step_ref
+    r, w, _ = D.init(backend="gloo")
+    grp = D.CfgGroup(r, w, size=2)
+    T, h, ww = 3, 4, 8
+    rows = T * h * ww
+    g = torch.Generator().manual_seed(5)
+    eps_full = torch.randn(2, rows, 4, generator=g).half()                     # what a B=2 forward would return (synthetic)
+    lat = torch.randn(1, T, 4, h, ww, generator=g)
+    guid = torch.linspace(1.0, 3.0, T)
+    outs = []
+    for step in range(3):                                                      # a few steps: the buffer is reused
+        eps_all = torch.zeros(2, rows, 4, dtype=torch.float16)
+        mine = None
+        for row in grp.rows():
+            mine = (eps_full[row].float() * (step + 1)).half()                  # "this rank's forward output" of its row
+            eps_all[row].copy_(mine)
+        grp.all_gather_rows(eps_all, mine)
+        e = eps_all.float().reshape(2, T, h, ww, 4).permute(0, 1, 4, 2, 3)
+        lat = euler_cfg_step_ref(e[0:1], e[1:2], lat, guid, 10.0 / (step + 1), 5.0 / (step + 1))
+        outs.append(eps_all.clone())
+    q.put((r, grp.rows(), grp.pair, grp.n_pairs, torch.stack(outs).numpy(), lat.numpy()))   # numpy: no fd passing after exit
+
+
+def test_cfg_pair_exchange_and_combine_match_single_rank():
+    """CFG-pair axis (north_star 'denoising-step batch'): rank 0 owns the unconditional row, rank 1 the conditional one; after
+    the per-step all_gather both ranks hold the full eps batch and the replicated CFG + Euler combine is bit-identical to the
+    single-rank result on the same eps."""
+    from oracle.reproject_ref import euler_cfg_step_ref
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_cfg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in ps), key=lambda t: t[0])
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0] and res[1][1] == [1] and res[0][2] == res[1][2] == 0 and res[0][3] == 1
+    T, h, ww = 3, 4, 8
+    g = torch.Generator().manual_seed(5)
+    eps_full = torch.randn(2, T * h * ww, 4, generator=g).half()
+    lat = torch.randn(1, T, 4, h, ww, generator=g)
+    guid = torch.linspace(1.0, 3.0, T)
+    for step in range(3):
+        e16 = (eps_full.float() * (step + 1)).half()
+        for r in res:
+            assert torch.equal(torch.from_numpy(r[4][step]), e16)                                 # both members hold both rows, in CFG order
+        e = e16.float().reshape(2, T, h, ww, 4).permute(0, 1, 4, 2, 3)
+        lat = euler_cfg_step_ref(e[0:1], e[1:2], lat, guid, 10.0 / (step + 1), 5.0 / (step + 1))
+    assert torch.equal(torch.from_numpy(res[0][5]), lat) and torch.equal(torch.from_numpy(res[1][5]), lat)          # replicated combine == single-rank combine, bit-exact
+
+
+def test_cfg_group_degenerate_and_validation():
+    import pytest
+    from evoworld_amd import distributed as D
+    g1 = D.CfgGroup(0, 1, size=1)
+    assert g1.rows() == [0, 1] and g1.n_pairs == 1
+    x = torch.arange(8.0).reshape(2, 2, 2)
+    assert g1.all_gather_rows(x, x[1]) is x                                    # no process group: nothing to exchange
+    with pytest.raises(ValueError):
+        D.CfgGroup(0, 3, size=2)
+    with pytest.raises(ValueError):
+        D.CfgGroup(0, 4, size=4)

@@ -173,6 +173,44 @@ def test_bench_one_rank_over_rccl_broadcasts_weights():
     assert line["n_gpus"] == 1 and line["config"]["valid"] is False and line["value"] > 0
 
 
+def test_cfg_pair_split_matches_batched_cfg(models):
+    """CFG-pair axis (evoworld_amd.distributed.CfgGroup; the CFG batch of pipeline_evoworld.py:691-711 split into two B=1
+    forwards + one eps gather per step): the degenerate one-rank group runs the same code path as a rank pair and must
+    reproduce the batched B=2 loop up to fp32 summation order of the GEMM tiles (M halves change the tile schedule)."""
+    from evoworld_amd.distributed import CfgGroup
+    cfg, ref, unet, Pipe = models
+    T, h, w, steps = 4, 16, 32, 5
+    g = torch.Generator().manual_seed(15)
+    lat0, il = torch.randn(1, T, 4, h, w, generator=g), torch.randn(1, T + 1, 4, h, w, generator=g)
+    ehs, pl = torch.randn(1, 1, cfg["cross_attention_dim"], generator=g), torch.randn(1, T, 6, h, w, generator=g)
+    kw = dict(height=h * 8, width=w * 8, num_frames=T, num_inference_steps=steps, latents=lat0, output_type="latent",
+              plucker_embedding=pl, image_latents=il, image_embeddings=ehs)
+    pipe = Pipe(unet=unet)
+    a = pipe(torch.zeros(1, 3, h * 8, w * 8), **kw).frames
+    pipe.cfg_group = CfgGroup(0, 1, size=1)
+    b = pipe(torch.zeros(1, 3, h * 8, w * 8), **kw).frames
+    e = rel_l2(b.cpu(), a.cpu())
+    print(f"CFG-pair split (two B=1 forwards + gather) vs batched CFG: rel-L2 {e:.2e}")
+    assert e < 1e-4
+
+
+def test_bench_cfg_split_one_rank_over_rccl():
+    """bench.py --split cfg with the process group forced on: the per-step eps exchange goes through a 1-rank RCCL group."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, EW_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--tiny", "--steps", "1", "--warmup", "0", "--denoise-steps", "2",
+                        "--height", "128", "--width", "256", "--no-cpu-baseline", "--split", "cfg"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["parallelism"] == "cfg1 x dp1" and line["scaling"] == "weak"
+
+
 @pytest.mark.skipif(not __import__("os").environ.get("EW_FULL_PARITY_STEPS"),
                     reason="full-size clip against the fp32 CPU oracle: ~3 min of host time per denoise step; EW_FULL_PARITY_STEPS=25 "
                            "(result committed under profiles/)")
