@@ -799,7 +799,10 @@ namespace {
 
 // half split of small problems: see launch3.  EW_G3_SKHALF_MINK = smallest K it is used for (0 = off; A/B hook)
 inline int sk_half_min_k() {
-    static const int v = getenv("EW_G3_SKHALF_MINK") ? atoi(getenv("EW_G3_SKHALF_MINK")) : 2560;
+    // A/B per shape at M = 7200, N = 1280 (profiles/r04_d_half_split.txt): K = 11520 conv 235 -> 222 us, K = 23040 conv 443 -> 396 us;
+    // K = 5120 dense 104 -> 115 us, K = 2560 67 -> 74, temporal K = 3840 90 -> 97 (the hand-over, 2 x 320 KB per block pair, costs more
+    // than the idle CUs there): on from K = 8192
+    static const int v = getenv("EW_G3_SKHALF_MINK") ? atoi(getenv("EW_G3_SKHALF_MINK")) : 8192;
     return v;
 }
 inline bool sk_half_shape(const GemmP& p, long long tiles) {

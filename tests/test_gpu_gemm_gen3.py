@@ -186,8 +186,8 @@ def test_streamk_tail_matches_whole_tile_schedule(case):
                                    rowbias=rb, rows_per_group=H * W, ld_rowbias=C)
         mk = lambda: torch.empty(M, C, dtype=torch.float16, device=DEV)
     elif case == "half_dense":               # round 4, HALF split: deepest-level feed-forward down projection, 116 tiles < 256 CUs
-        M, N, K = 7200, 1280, 5120
-        x, w, b = rnd(M, K).half().to(DEV), (rnd(N, K) / 48).half().to(DEV), rnd(N).half().to(DEV)
+        M, N, K = 7200, 1280, 10240          # (the default threshold is K >= 8192)
+        x, w, b = rnd(M, K).half().to(DEV), (rnd(N, K) / 64).half().to(DEV), rnd(N).half().to(DEV)
         r1 = ops.Res.from_float(rnd(M, N).to(DEV) * 3)
         run = lambda out: ops.gemm(x, w, out, M=M, N=N, c1=K, lda=K, bias=b, r1=r1, ld_r1=N)
         mk = lambda: ops.Res.empty(M, N, DEV, True)

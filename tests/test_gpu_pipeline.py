@@ -175,11 +175,14 @@ def test_bench_one_rank_over_rccl_broadcasts_weights():
 
 def test_cfg_pair_split_matches_batched_cfg(models):
     """CFG-pair axis (evoworld_amd.distributed.CfgGroup; the CFG batch of pipeline_evoworld.py:691-711 split into two B=1
-    forwards + one eps gather per step): the degenerate one-rank group runs the same code path as a rank pair and must
-    reproduce the batched B=2 loop up to fp32 summation order of the GEMM tiles (M halves change the tile schedule)."""
+    forwards + one eps gather per step): the degenerate one-rank group runs the same code path as a rank pair.  A B=1 forward is
+    not bit-identical to the same row inside a B=2 forward (tile schedule / stream-K split / GroupNorm chunking depend on M, so
+    fp32 summation order differs and fp16 roundings flip: another realisation of the same rounding noise, measured 8.0e-4 between
+    the two clips) -- so the split clip is held to the SAME tolerance against the fp32 oracle as the batched one, and the two
+    to each other within two noise realisations."""
     from evoworld_amd.distributed import CfgGroup
     cfg, ref, unet, Pipe = models
-    T, h, w, steps = 4, 16, 32, 5
+    T, h, w, steps = 4, 16, 32, 3
     g = torch.Generator().manual_seed(15)
     lat0, il = torch.randn(1, T, 4, h, w, generator=g), torch.randn(1, T + 1, 4, h, w, generator=g)
     ehs, pl = torch.randn(1, 1, cfg["cross_attention_dim"], generator=g), torch.randn(1, T, 6, h, w, generator=g)
@@ -189,9 +192,12 @@ def test_cfg_pair_split_matches_batched_cfg(models):
     a = pipe(torch.zeros(1, 3, h * 8, w * 8), **kw).frames
     pipe.cfg_group = CfgGroup(0, 1, size=1)
     b = pipe(torch.zeros(1, 3, h * 8, w * 8), **kw).frames
-    e = rel_l2(b.cpu(), a.cpu())
-    print(f"CFG-pair split (two B=1 forwards + gather) vs batched CFG: rel-L2 {e:.2e}")
-    assert e < 1e-4
+    b2 = pipe(torch.zeros(1, 3, h * 8, w * 8), **kw).frames
+    want = _oracle_loop(ref, lat0, il, ehs, pl, T, steps)
+    ea, eb, eab = rel_l2(a.cpu(), want), rel_l2(b.cpu(), want), rel_l2(b.cpu(), a.cpu())
+    print(f"CFG-pair split vs fp32 oracle {eb:.3e} (batched CFG: {ea:.3e}); split vs batched {eab:.2e}")
+    assert torch.equal(b, b2)                      # the split path is deterministic too
+    assert ea < TOL_CLIP3 and eb < TOL_CLIP3 and eab < 2 * TOL_CLIP3
 
 
 def test_bench_cfg_split_one_rank_over_rccl():
