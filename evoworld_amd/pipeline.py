@@ -260,15 +260,23 @@ class StableVideoDiffusionPipeline:
         num_frames = num_frames if num_frames is not None else self.unet.config.num_frames
         decode_chunk_size = decode_chunk_size if decode_chunk_size is not None else num_frames
         if num_videos_per_prompt != 1:
-            raise NotImplementedError("num_videos_per_prompt != 1: one video per call (the conditioning tensors of the reference "
-                                      "path -- plucker_embedding, memorized_pixel_values -- are not repeated there either)")
+            # the reference repeats image latents / embeddings num_videos_per_prompt times (:292-294, :316) but NOT plucker_embedding,
+            # so its conditioning concat (:639-640) fails with a batch mismatch for any value but 1
+            raise ValueError("num_videos_per_prompt must be 1: plucker_embedding / memorized_pixel_values are per clip "
+                             "(the reference's own conditioning concat, pipeline_evoworld.py:639-640, needs matching batch sizes)")
         self.check_inputs(image, height, width)
         image = self._image_to_tensor(image, height, width)
         if plucker_embedding is None:
-            raise ValueError("plucker_embedding [1,T,6,h,w] is required (evoworld conditioning)")
+            raise ValueError("plucker_embedding [B,T,6,h,w] is required (evoworld conditioning)")
         batch_size = image.shape[0]
         if batch_size != 1:
-            raise NotImplementedError("one clip per call (the reference callers pass batch 1); shard clips across ranks")
+            return self._call_batched(image, dict(
+                height=height, width=width, num_frames=num_frames, num_inference_steps=num_inference_steps, sigmas=sigmas,
+                min_guidance_scale=min_guidance_scale, max_guidance_scale=max_guidance_scale, fps=fps, motion_bucket_id=motion_bucket_id,
+                noise_aug_strength=noise_aug_strength, decode_chunk_size=decode_chunk_size, output_type=output_type,
+                callback_on_step_end=callback_on_step_end, callback_on_step_end_tensor_inputs=callback_on_step_end_tensor_inputs,
+                mask_mem=mask_mem), generator, latents, plucker_embedding, memorized_plucker_embedding, memorized_pixel_values,
+                image_latents, image_embeddings, image_noise, return_dict)
         self._guidance_scale = max_guidance_scale
         cfg = self.do_classifier_free_guidance
 
@@ -339,6 +347,48 @@ class StableVideoDiffusionPipeline:
         if not return_dict:
             return frames
         return StableVideoDiffusionPipelineOutput(frames=frames)
+
+    def _call_batched(self, image, kw, generator, latents, plucker, mem_plucker, memory, image_latents, image_embeddings, image_noise,
+                      return_dict):
+        """Batch B > 1 (pipeline_evoworld.py:573-578: batch_size = image.shape[0]): the clips of a batch are independent, so they
+        run one after the other through the single-clip path -- each with its own [uncond, cond] U-Net batch -- after the RANDOM
+        DRAWS have been made for the whole batch exactly as the reference makes them: one [(B*(1+T)),3,H,W] augmentation-noise
+        tensor (:596-599), then one [B,T,4,h,w] latents tensor (:660-671), sliced per clip."""
+        dev = self._device
+        B, T = image.shape[0], kw["num_frames"]
+        H, W = kw["height"], kw["width"]
+        if isinstance(generator, list):
+            if len(generator) != B:
+                raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective "
+                                 f"batch size of {B}.")
+            raise ValueError("a list of generators with batch > 1 is not supported (the reference's randn_tensor call for the "
+                             "augmentation noise indexes the list by (batch x frame) and fails too); pass one generator")
+        for name, t in (("plucker_embedding", plucker), ("memorized_pixel_values", memory), ("latents", latents),
+                        ("image_latents", image_latents), ("image_embeddings", image_embeddings)):
+            if t is not None and t.shape[0] != B:
+                raise ValueError(f"{name} has batch {t.shape[0]} but image has batch {B}")
+        n_cond = (1 + memory.shape[1]) if memory is not None else (image_latents.shape[1] if image_latents is not None else 1 + T)
+        if image_noise is None and (image_latents is None or image_embeddings is None or isinstance(generator, torch.Generator)):
+            image_noise = _randn_like_reference((B * n_cond, 3, H, W), generator, dev)                     # draw #1, whole batch
+        if latents is None:
+            latents = _randn_like_reference((B, T, 4, H // self.vae_scale_factor, W // self.vae_scale_factor), generator, dev)   # draw #2
+        outs = []
+        for b in range(B):
+            sl = slice(b, b + 1)
+            outs.append(self(image[sl], **kw, generator=None, latents=latents[sl], return_dict=False,
+                             plucker_embedding=plucker[sl], memorized_plucker_embedding=None if mem_plucker is None else mem_plucker[sl],
+                             memorized_pixel_values=None if memory is None else memory[sl],
+                             image_latents=None if image_latents is None else image_latents[sl],
+                             image_embeddings=None if image_embeddings is None else image_embeddings[sl],
+                             image_noise=None if image_noise is None else image_noise[b * n_cond:(b + 1) * n_cond]))
+        if isinstance(outs[0], torch.Tensor):
+            frames = torch.cat(outs, dim=0)
+        elif isinstance(outs[0], list):
+            frames = [clip for o in outs for clip in o]
+        else:
+            import numpy as np
+            frames = np.concatenate(outs, axis=0)
+        return StableVideoDiffusionPipelineOutput(frames=frames) if return_dict else frames
 
     def decode_latents(self, latents, num_frames, decode_chunk_size=14):
         latents = latents.flatten(0, 1) / self.vae.config.scaling_factor                     # :360-362

@@ -42,12 +42,12 @@ T, H, W = 4, 128, 256
 STEPS = 25
 
 
-def case_inputs(seed):
+def case_inputs(seed, B=1):
     """Seeded call arguments of one glue case (the test rebuilds nothing: these are stored in the fixture)."""
     g = torch.Generator().manual_seed(seed)
-    image = torch.rand(1, 3, H, W, generator=g) * 2 - 1
-    memory = torch.rand(1, T, 3, H, W, generator=g) * 2 - 1
-    plucker = torch.randn(1, T, 6, H // 8, W // 8, generator=g)
+    image = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    memory = torch.rand(B, T, 3, H, W, generator=g) * 2 - 1
+    plucker = torch.randn(B, T, 6, H // 8, W // 8, generator=g)
     return image.half().float(), memory.half().float(), plucker     # pixels on the fp16 grid: stored as fp16 in the fixture
 
 
@@ -135,11 +135,12 @@ def pipeline_goldens(P):
     fe = CLIPImageProcessor()          # default image_mean / image_std = the OpenAI CLIP statistics
     gold = {"T": np.int64(T), "H": np.int64(H), "W": np.int64(W), "steps": np.int64(STEPS), "unet_seed": np.int64(UNET_SEED),
             "image_mean": np.asarray(fe.image_mean, np.float32), "image_std": np.asarray(fe.image_std, np.float32)}
-    cases = [("mem", 21, False, dict()),
+    cases = [("mem", 21, False, dict(), 1),
              ("mask", 22, True, dict(min_guidance_scale=1.5, max_guidance_scale=4.0, fps=9, motion_bucket_id=63,
-                                     noise_aug_strength=0.05))]
-    for tag, seed, mask_mem, extra in cases:
-        image, memory, plucker = case_inputs(seed)
+                                     noise_aug_strength=0.05), 1),
+             ("b2", 23, False, dict(), 2)]          # batch of two clips (:573-578): one noise draw / one latents draw for the batch
+    for tag, seed, mask_mem, extra, B in cases:
+        image, memory, plucker = case_inputs(seed, B)
         unet = UNetShim(ref, cfg)
         pipe = P.StableVideoDiffusionPipeline(vae=StandInVAE(), image_encoder=StandInCLIP(cfg["cross_attention_dim"]), unet=unet,
                                               scheduler=EulerDiscreteScheduler(), feature_extractor=fe)
@@ -150,6 +151,12 @@ def pipeline_goldens(P):
                    callback_on_step_end=lambda p, i, t, kw: trace.append(kw["latents"].clone()) or {}, **extra)
         c0 = unet.calls[0]
         assert len(unet.calls) == STEPS and len(trace) == STEPS
+        if B > 1:                        # batch case: inputs, step-0 model input ([2B,...]: B uncond rows, then B cond rows) and the result
+            gold.update({f"{tag}_image": image.half().numpy(), f"{tag}_memory": memory.half().numpy(), f"{tag}_plucker": plucker.numpy(),
+                         f"{tag}_step0_latent_model_input": c0["sample"].numpy(), f"{tag}_final_latents": out.frames.numpy(),
+                         f"{tag}_rng_state_after": gen.get_state().numpy()[:64].copy()})
+            print(tag, "final latents", tuple(out.frames.shape))
+            continue
         gold.update({
             f"{tag}_image": image.half().numpy(), f"{tag}_memory": memory.half().numpy(), f"{tag}_plucker": plucker.numpy(),
             f"{tag}_mask_mem": np.bool_(mask_mem),

@@ -123,3 +123,44 @@ def test_navigator_window_vs_reference_run(tag):
     assert rec["noise_aug_strength"] == float(g[f"{tag}_noise_aug_strength"])
     assert torch.equal(rec["image"].cpu(), torch.from_numpy(g[f"{tag}_image_passed"]))
     assert torch.equal(rec["memorized_pixel_values"], nav.memorized_images) and rec["memorized_pixel_values"] is not nav.memorized_images
+
+
+def test_pipeline_batch_of_two_vs_reference_run(gold, hip_unet):
+    """Batch B = 2 (pipeline_evoworld.py:573-578): the reference draws ONE augmentation-noise tensor and ONE latents tensor for the
+    whole batch and runs a 2B-row U-Net batch; the build makes the same two draws and runs the clips one after the other."""
+    from types import SimpleNamespace
+    from evoworld_amd.pipeline import StableVideoDiffusionPipeline
+    from oracle.standins import StandInCLIP, StandInVAE
+    cfg, unet = hip_unet
+    T, H, W, steps = int(gold["T"]), int(gold["H"]), int(gold["W"]), int(gold["steps"])
+    h, w = H // 8, W // 8
+    image = torch.from_numpy(gold["b2_image"]).float().cuda()
+    memory = torch.from_numpy(gold["b2_memory"]).float().cuda()
+    pl = torch.from_numpy(gold["b2_plucker"])
+    fe = SimpleNamespace(image_mean=gold["image_mean"].tolist(), image_std=gold["image_std"].tolist())
+    pipe = StableVideoDiffusionPipeline(unet=unet, vae=StandInVAE(), image_encoder=StandInCLIP(cfg["cross_attention_dim"]),
+                                        feature_extractor=fe)
+    seen = []
+    real = unet.forward_nhwc
+
+    def spy(x_in, *a, **k):
+        seen.append(x_in[:, :18].float().reshape(2, T, h, w, 18).permute(0, 1, 4, 2, 3).cpu())
+        return real(x_in, *a, **k)
+    unet.forward_nhwc = spy
+    try:
+        gen = torch.manual_seed(-1)
+        out = pipe(image, height=H, width=W, num_frames=T, num_inference_steps=steps, generator=gen, decode_chunk_size=8,
+                   output_type="latent", plucker_embedding=pl, memorized_pixel_values=memory, mask_mem=False).frames
+    finally:
+        unet.forward_nhwc = real
+    assert out.shape == (2, T, 4, h, w) and len(seen) == 2 * steps
+    assert np.array_equal(gen.get_state().numpy()[:64], gold["b2_rng_state_after"])          # two draws, batch-sized, in order
+    g0 = torch.from_numpy(gold["b2_step0_latent_model_input"])                               # rows: uncond clip 0, 1, cond clip 0, 1
+    for b in range(2):
+        mine = seen[b * steps]                                                                # [uncond, cond] of clip b at its step 0
+        e = rel_l2(mine, torch.stack([g0[b], g0[2 + b]]))
+        print(f"[b2] clip {b} step-0 model input vs reference run: {e:.2e}")
+        assert e < 5e-4
+    e = rel_l2(out.cpu(), torch.from_numpy(gold["b2_final_latents"]))
+    print(f"[b2] final latents of the batch vs reference run: {e:.3e}")
+    assert e < 1e-3
