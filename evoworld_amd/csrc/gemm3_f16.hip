@@ -906,7 +906,8 @@ ew_status dispatch_epi3(const GemmP& p, hipStream_t s) {
 
 // true when generation 3 can run the problem AND is expected to be the faster choice (enough 256x320 tiles to fill the chip)
 bool EW3_NAME(ew_gemm3_wants)(const GemmP& p) {
-    if (p.N % BN != 0 || p.M < 4 * BM) return false;
+    static const int min_m = getenv("EW_G3_MINM") ? atoi(getenv("EW_G3_MINM")) : 4 * BM;       // A/B hook (the V^T projections have M = C)
+    if (p.N % BN != 0 || p.M < min_m) return false;
     if (BN != 320 && p.N % 320 == 0) return false;                      // the 320-wide instance takes what it can
     if ((long long)ew_cdiv(p.M, BM) * (p.N / BN) > 256LL * (ITEMS_BYTES / 16 - 4)) return false;     // work-item table of a persistent block
     // GELU (CLIP's fc1) is only compiled into the plain dense variant: the erf code in every epilogue cost the conv variants
