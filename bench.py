@@ -152,7 +152,8 @@ def kernel_breakdown(unet, pipe, latents, image_latents, ehs, plucker, T, h, w, 
                     if n == "ew_layernorm_f16":
                         key += f" rows={a[9]} C={a[10]}"
                     elif n.startswith("ew_groupnorm") and n != "ew_groupnorm_finalize":
-                        key += f" slabs={a[-9] if n.endswith('apply_f16') else a[3]}"
+                        o_ = 6 if n.endswith('apply_f16') else 3
+                        key += f" slabs={a[o_]} rows={a[o_ + 1]} C={a[o_ + 2]}" + (" +lo" if a[1] else "")
                     elif n.startswith("ew_attn_spatial"):
                         key += f" S={a[5]}"
                 if n.startswith("ew_attn_spatial"):

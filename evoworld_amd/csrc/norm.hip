@@ -3,6 +3,7 @@
 // Reference call sites: torch.nn.GroupNorm / LayerNorm inside the diffusers blocks instantiated by
 // evoworld/trainer/unet_plucker.py:161-233, conv_norm_out :236/478.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -19,8 +20,9 @@ namespace {
 // The chunking depends on (rows, n_slabs) only, so the two sources of a virtual channel concat share one partial buffer.
 // x_lo (may be null): lo8 companion of a split residual stream (common.h: one byte per element, same element strides).
 // ---------------------------------------------------------------------------------------------
-__host__ __device__ inline int gn_chunks(int n_slabs, int rows) {
-    int want = (640 + n_slabs - 1) / n_slabs;                  // ~2.5 blocks per CU over the whole launch
+inline int gn_chunks(int n_slabs, int rows) {
+    static const int target = getenv("EW_GN_BLOCKS") ? atoi(getenv("EW_GN_BLOCKS")) : 640;     // A/B hook
+    int want = (target + n_slabs - 1) / n_slabs;               // ~2.5 blocks per CU over the whole launch
     const int cap = (rows + 63) / 64;                          // at least 64 rows per chunk
     if (want > cap) want = cap;
     if (want > 512) want = 512;
@@ -418,7 +420,8 @@ extern "C" ew_status ew_groupnorm_apply_f16(const void* x, const void* x_lo, con
     const int VPP = C_src / 8;
     EW_REQUIRE(VPP <= 1024, "ew_groupnorm_apply_f16: C_src too large");
     const int PL = VPP >= 256 ? 1 : 256 / VPP;
-    const int rpb = 32 * PL;                                   // 32 vectors in flight per thread-column
+    static const int apply_rows = getenv("EW_GN_APPLY_ROWS") ? atoi(getenv("EW_GN_APPLY_ROWS")) : 32;   // A/B hook
+    const int rpb = apply_rows * PL;                           // 32 vectors in flight per thread-column
     const GnWs w = gn_ws((float*)ws, n_slabs, rows, C_tot);
     dim3 grid(ew_cdiv(rows, rpb), n_slabs);
     if (x_lo)
