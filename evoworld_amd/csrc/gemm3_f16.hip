@@ -906,7 +906,10 @@ ew_status dispatch_epi3(const GemmP& p, hipStream_t s) {
 
 // true when generation 3 can run the problem AND is expected to be the faster choice (enough 256x320 tiles to fill the chip)
 bool EW3_NAME(ew_gemm3_wants)(const GemmP& p) {
-    static const int min_m = getenv("EW_G3_MINM") ? atoi(getenv("EW_G3_MINM")) : 4 * BM;       // A/B hook (the V^T projections have M = C)
+    // smallest M: the swapped-operand V^T projections (M = C = 320 / 640 / 1280 rows of W_v against N = all tokens) measured
+    // 337 -> 253 us (level 0) and 192 -> 156 us (level 1) here against generation 2's 256x160 tiles (640-byte instead of 320-byte output
+    // row pieces; profiles/r04_f_sweeps.txt); EW_G3_MINM is the A/B hook (round 3 value: 1024)
+    static const int min_m = getenv("EW_G3_MINM") ? atoi(getenv("EW_G3_MINM")) : 320;
     if (p.N % BN != 0 || p.M < min_m) return false;
     if (BN != 320 && p.N % 320 == 0) return false;                      // the 320-wide instance takes what it can
     if ((long long)ew_cdiv(p.M, BM) * (p.N / BN) > 256LL * (ITEMS_BYTES / 16 - 4)) return false;     // work-item table of a persistent block

@@ -51,16 +51,20 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, const int8_t* __restr
     // eight independent 16-byte loads in flight per thread (one dependent load per iteration ran at 3.3 TB/s, four at 3.8)
     int r = r0 + pl;
     if (base_lo) {
-        for (; r + 3 * PL < r1; r += 4 * PL) {
-            f16x8 val[4];
-            u32x2 vlo[4];
+#ifndef EW_GN_STATS_UNROLL
+#define EW_GN_STATS_UNROLL 8      /* round 4 A/B: level-0 statistics pass 109 -> 102.5 us (profiles/r04_f_sweeps.txt) */
+#endif
+        constexpr int UL = EW_GN_STATS_UNROLL;      // rows in flight per thread on the hi + lo8 path (A/B: 4 vs 8)
+        for (; r + (UL - 1) * PL < r1; r += UL * PL) {
+            f16x8 val[UL];
+            u32x2 vlo[UL];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UL; ++u) {
                 val[u] = *(const f16x8*)(base + (size_t)(r + u * PL) * C_src);
                 vlo[u] = *(const u32x2*)(base_lo + (size_t)(r + u * PL) * C_src);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UL; ++u) {
                 float xv[8];
                 ew_split_dec8(val[u], vlo[u], xv);
 #pragma unroll
@@ -420,8 +424,8 @@ extern "C" ew_status ew_groupnorm_apply_f16(const void* x, const void* x_lo, con
     const int VPP = C_src / 8;
     EW_REQUIRE(VPP <= 1024, "ew_groupnorm_apply_f16: C_src too large");
     const int PL = VPP >= 256 ? 1 : 256 / VPP;
-    static const int apply_rows = getenv("EW_GN_APPLY_ROWS") ? atoi(getenv("EW_GN_APPLY_ROWS")) : 32;   // A/B hook
-    const int rpb = apply_rows * PL;                           // 32 vectors in flight per thread-column
+    static const int apply_rows = getenv("EW_GN_APPLY_ROWS") ? atoi(getenv("EW_GN_APPLY_ROWS")) : 8;    // A/B hook
+    const int rpb = apply_rows * PL;                           // rows per block: 8 per thread column (round 4: 32 -> 8, level-0 apply 139 -> 127 us: smaller blocks, better balance)
     const GnWs w = gn_ws((float*)ws, n_slabs, rows, C_tot);
     dim3 grid(ew_cdiv(rows, rpb), n_slabs);
     if (x_lo)

@@ -49,7 +49,9 @@ def both(lib, fn):
 @pytest.mark.parametrize("M,N,K,eps", [(51237, 320, 320, "bias"), (26011, 640, 192, "rb+r1"), (26000, 640, 128, "r1+r2"),
                                         (51456, 320, 64, "silu"), (25700, 640, 448, "rb"), (30000, 960, 64, "rb+r1+r2"),
                                         # weight matrix > 3 MB: banded tile order (8 tile columns = 2 bands; 6 = one full + one ragged band)
-                                        (6500, 2560, 640, "bias"), (8811, 1920, 1024, "r1")])
+                                        (6500, 2560, 640, "bias"), (8811, 1920, 1024, "r1"),
+                                        # round 4: M = C (the swapped-operand V^T projections: W_v rows against all tokens), ragged second row tile
+                                        (320, 32000, 320, "bias")])
 def test_dense_epilogues(ops, lib, M, N, K, eps):
     x, w, b = rnd(M, K, seed=1).half().to(DEV), (rnd(N, K, seed=2) / math.sqrt(K)).half().to(DEV), rnd(N, seed=3).half().to(DEV)
     rpg = 7001
