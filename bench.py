@@ -39,15 +39,17 @@ def source_fingerprint():
 
 
 def committed_traffic(residual_mode):
-    """HBM bytes of ONE U-Net forward from the committed rocprofv3 PMC run (profiles/r03_hbm_traffic.json: separate
+    """HBM bytes of ONE U-Net forward from the committed rocprofv3 PMC run (profiles/rNN_hbm_traffic.json, latest round: separate
     --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.sh).
     PMC collection needs its own profiler passes, so this is a RECORDED measurement: it carries the fingerprint of the sources
     and the residual-stream mode it was taken on, and is reported as stale (traffic = null in the bench line) when either
     differs from what is running."""
-    f = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic.json")))      # the latest round's record
     try:
-        tr = json.load(open(f))
-    except (OSError, ValueError):
+        tr = json.load(open(files[-1]))
+        tr["file"] = os.path.relpath(files[-1], ROOT)
+    except (OSError, ValueError, IndexError):
         return None
     rec = tr.get("recorded_at", {})
     tr["stale"] = not (rec.get("source_fingerprint") == source_fingerprint() and rec.get("residual_stream") == residual_mode)
