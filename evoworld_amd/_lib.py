@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EW_LIB_PATH") or os.path.join(_HERE, "libevoworld_hip.so")   # EW_LIB_PATH: ablation builds (tools/)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # every symbol declared in include/evoworld_hip.h
 SYMBOLS = [
@@ -48,7 +48,7 @@ class FfArgs(ctypes.Structure):
         ("zero_page", c_void_p), ("M", c_int), ("C", c_int), ("hidden", c_int), ("rows_per_group", c_int), ("ld_rowbias", c_int),
         ("c_acc", c_float), ("c_r1", c_float), ("c_r2", c_float),
         ("x_lo", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("addvec", c_void_p), ("add_rows_per_group", c_int),
-        ("ln_eps", c_float),
+        ("ln_eps", c_float), ("ln_folded", c_int),
     ]
 
 

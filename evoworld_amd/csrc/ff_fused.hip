@@ -100,7 +100,7 @@ struct FfP {
 #define FF_ABL 0          /* ablation builds (tools/experiments): 1 no GEGLU math, 2 no DMA, 4 no epilogue, 8 no up-proj MFMA, 16 no down-proj MFMA */
 #endif
 
-template <bool LO, bool R2, bool XLO>
+template <bool LO, bool R2, int XLO>      // XLO: 0 = x as given (or the ln_gamma prologue on a plain fp16 x), 1 = ln_gamma prologue on hi + lo8, 2 = folded LayerNorm: normalise only
 __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
     // ---- x fragments of this wave's 32 rows of a tile: row frow (+16 rf), k = ks*32 + fks*8 .. +8 (both waves of an M pair hold
     // the same rows).  The NEXT tile's fragments are requested before the epilogue of the current one.
     f16x8 xf[RF][KS];
-    u32x2 xl[RF][XLO ? KS : 1];                 // lo8 companions of the LayerNorm input stream
+    u32x2 xl[RF][XLO == 1 ? KS : 1];            // lo8 companions of the LayerNorm input stream
     auto load_x = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
         for (int rf = 0; rf < RF; ++rf) {
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
             const f16* xp = p.x + (size_t)m * C + fks * 8;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) xf[rf][ks] = *(const f16x8*)(xp + ks * 32);
-            if constexpr (XLO) {
+            if constexpr (XLO == 1) {
                 const int8_t* lp = p.x_lo + (size_t)m * C + fks * 8;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) xl[rf][ks] = *(const u32x2*)(lp + ks * 32);
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float t;
-                    if constexpr (XLO) t = ew_split_dec(xf[rf][ks][e], ew_sbyte(xl[rf][ks][e >> 2], e & 3));
+                    if constexpr (XLO == 1) t = ew_split_dec(xf[rf][ks][e], ew_sbyte(xl[rf][ks][e >> 2], e & 3));
                     else t = (float)xf[rf][ks][e];
                     v[e] = t + (float)av[e];
                 }
@@ -238,13 +238,44 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
             }
         }
     };
+    // Folded LayerNorm (XLO == 2, round 4): gamma / beta live in the packs (W1 diag(gamma), b1 + W1 beta), so the prologue is pure
+    // register arithmetic on the fragments -- two-pass fp32 statistics over the row's 320 fp16 values (4 lanes x 80), normalise in place.
+    auto norm_x = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int rf = 0; rf < RF; ++rf) {
+            float sum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += (float)xf[rf][ks][e];
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float mean = sum * (1.0f / C);
+            float sq = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = (float)xf[rf][ks][e] - mean; sq = fmaf(d, d, sq); }
+            sq += __shfl_xor(sq, 16, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            const float rstd = rsqrtf(sq * (1.0f / C) + p.ln_eps);
+            const float nmr = -mean * rstd;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)fmaf((float)xf[rf][ks][e], rstd, nmr);
+                xf[rf][ks] = o;
+            }
+        }
+    };
     load_x((int)blockIdx.x);
     FF_WAIT_VM0();
 
     for (int ti = 0; ti < n_my; ++ti) {
         const int tile = (int)blockIdx.x + ti * G;
         const int m_w0 = tile * BM + wm * WROWS;
-        if (p.ln_gamma) ln_x(tile);
+        if constexpr (XLO == 2) norm_x(); else if (p.ln_gamma) ln_x(tile);
         f32x4 acc2[RF][NJ2];
 #pragma unroll
         for (int rf = 0; rf < RF; ++rf)
@@ -521,6 +552,7 @@ extern "C" ew_status ew_ff_geglu320_f16(const ew_ff_args* a, void* stream) {
     EW_REQUIRE((long long)a->M * C * 2 < (1LL << 40), "ew_ff_geglu320_f16: M too large");
     EW_REQUIRE((a->ln_gamma != nullptr) == (a->ln_beta != nullptr), "ew_ff_geglu320_f16: ln_gamma and ln_beta go together");
     EW_REQUIRE(a->ln_gamma || (!a->x_lo && !a->addvec), "ew_ff_geglu320_f16: x_lo / addvec need the LayerNorm prologue (ln_gamma)");
+    EW_REQUIRE(!a->ln_folded || (!a->ln_gamma && a->ln_eps > 0.f), "ew_ff_geglu320_f16: ln_folded excludes ln_gamma and needs ln_eps > 0");
     FfP p;
     p.x = (const f16*)a->x; p.w1p = (const f16*)a->w1p; p.b1p = (const f16*)a->b1p; p.w2p = (const f16*)a->w2p; p.b2 = (const f16*)a->b2;
     p.rowbias = (const f16*)a->rowbias; p.r1 = (const f16*)a->r1; p.r2 = (const f16*)a->r2;
@@ -549,12 +581,16 @@ extern "C" ew_status ew_ff_geglu320_f16(const ew_ff_args* a, void* stream) {
         hipLaunchKernelGGL((ff320_kernel<LO_, R2_, XLO_>), dim3(grid), dim3(64 * NWV), LDS_BYTES, s, p);                   \
     } while (0)
     const bool xlo = a->x_lo != nullptr;
-    if (lo && r2 && xlo) FF_LAUNCH(true, true, true);
-    else if (lo && r2) FF_LAUNCH(true, true, false);
-    else if (lo && xlo) FF_LAUNCH(true, false, true);
-    else if (lo) FF_LAUNCH(true, false, false);
-    else if (r2) FF_LAUNCH(false, true, false);
-    else FF_LAUNCH(false, false, false);
+    if (a->ln_folded) {                      // folded LayerNorm: the two operand sets the U-Net uses (anything else runs on the superset)
+        if (r2) FF_LAUNCH(true, true, 2);
+        else FF_LAUNCH(true, false, 2);
+    }
+    else if (lo && r2 && xlo) FF_LAUNCH(true, true, 1);
+    else if (lo && r2) FF_LAUNCH(true, true, 0);
+    else if (lo && xlo) FF_LAUNCH(true, false, 1);
+    else if (lo) FF_LAUNCH(true, false, 0);
+    else if (r2) FF_LAUNCH(false, true, 0);
+    else FF_LAUNCH(false, false, 0);
 #undef FF_LAUNCH
     return ew_check_launch("ew_ff_geglu320_f16");
 }

@@ -480,10 +480,16 @@ def gemm_fp8(a, a_scale, w, w_scale, out=None):
     return out
 
 
-def ff_pack(w1, b1, w2):
+def ff_pack(w1, b1, w2, ln=None):
     """Weights of one GEGLU feed-forward (w1 [2*H, C] value rows then gate rows, b1 [2*H], w2 [C, H]; fp32 or fp16, on the
-    device) -> (w1p, b1p, w2p) fp16 in the LDS-image packs ew_ff_geglu320_f16 streams (layout: csrc/ff_fused.hip)."""
+    device) -> (w1p, b1p, w2p) fp16 in the LDS-image packs ew_ff_geglu320_f16 streams (layout: csrc/ff_fused.hip).
+    ln = (gamma, beta) folds the affine part of the LayerNorm in front of the feed-forward into the up-projection (in fp32, before the
+    single rounding to fp16): LN(x) W1^T + b1 = ((x - mean) rstd) (W1 diag(gamma))^T + (b1 + W1 beta) -- for ff_geglu320(..., ln_folded=True)."""
     dev = w1.device
+    if ln is not None:
+        g, bt = ln[0].float().to(dev), ln[1].float().to(dev)
+        b1 = b1.float() + w1.float() @ bt
+        w1 = w1.float() * g[None, :]
     H2, C = w1.shape
     H = H2 // 2
     assert C == 320 and H == 1280 and tuple(w2.shape) == (C, H)
@@ -511,10 +517,11 @@ def ff_pack(w1, b1, w2):
 
 
 def ff_geglu320(x, pack, b2, out, *, rowbias=None, rows_per_group=1, ld_rowbias=None, r1=None, r2=None, c_acc=1.0, c_r1=1.0, c_r2=1.0,
-                ln=None, ln_eps=1e-5, addvec=None, add_rows_per_group=1):
+                ln=None, ln_eps=1e-5, addvec=None, add_rows_per_group=1, ln_folded=False):
     """out = c_acc * (GEGLU(n W1^T + b1) W2^T + b2 + rowbias) + c_r1 * r1 + c_r2 * r2 for 320-channel tokens, one kernel
     (ew_ff_geglu320_f16): pack = ff_pack(...); r1 / r2 / out tensors or `Res`.  n = x (fp16 [M, 320]), or with ln = (gamma, beta):
-    n = LayerNorm(x + addvec[m // add_rows_per_group]) computed in the kernel's prologue from the stream x (tensor or `Res`)."""
+    n = LayerNorm(x + addvec[m // add_rows_per_group]) computed in the kernel's prologue from the stream x (tensor or `Res`); with
+    ln_folded=True: n = (x - mean) * rstd of the hi plane of x, the LayerNorm's gamma / beta folded into the pack (ff_pack(..., ln=...))."""
     lib = _lib.load()
     x, x_lo = _hl(x)
     _req(x, torch.float16, "x")
@@ -522,6 +529,9 @@ def ff_geglu320(x, pack, b2, out, *, rowbias=None, rows_per_group=1, ld_rowbias=
     if ln is not None:
         a.x_lo, a.ln_gamma, a.ln_beta, a.addvec = _ptr(x_lo), _ptr(ln[0]), _ptr(ln[1]), _ptr(addvec)
         a.add_rows_per_group, a.ln_eps = add_rows_per_group, ln_eps
+    if ln_folded:
+        assert ln is None and addvec is None, "ln_folded: the LayerNorm's gamma / beta live in the pack (ff_pack(..., ln=...))"
+        a.ln_folded, a.ln_eps = 1, ln_eps
     r1h, r1l = _hl(r1)
     r2h, r2l = _hl(r2)
     oh, ol = _hl(out)

@@ -423,6 +423,9 @@ class UNetSpatioTemporalConditionModel:
                     # level 0: the LayerNorm + GEGLU feed-forward pairs run as ONE kernel (ew_ff_geglu320_f16) on LDS-image packs
                     for nm, ff in ((f"{tag}_ffp", ".ff"),) + (((f"{tag}_fip", ".ff_in"),) if tag == "t" else ()):
                         d[nm] = ops.ff_pack(f32(b + ff + ".net.0.proj.weight"), f32(b + ff + ".net.0.proj.bias"), f32(b + ff + ".net.2.weight"))
+                    if True:                    # norm3 folded into the up-projection of .ff (round 4, EW_FUSED_FF=3): W1 diag(gamma), b1 + W1 beta
+                        d[f"{tag}_ffp_ln"] = ops.ff_pack(f32(b + ".ff.net.0.proj.weight"), f32(b + ".ff.net.0.proj.bias"), f32(b + ".ff.net.2.weight"),
+                                                         ln=(f32(b + ".norm3.weight"), f32(b + ".norm3.bias")))
             W[t.p] = d
         W["cv_w"], W["cv_b"] = h(torch.cat(cv_w)), h(torch.cat(cv_b))
         self._cv_total = off
@@ -536,7 +539,9 @@ class UNetSpatioTemporalConditionModel:
         h = ops.linear(ao, d["s_ow"], d["s_ob"], out=self._res(rows, C, dev), rowbias=cv_s, rows_per_group=T * S,
                        ld_rowbias=self._cv_total, r1=h, ld_r1=C)
         fused = self.fused_ff if "s_ffp" in d else 0     # level 0: LayerNorm + GEGLU up-projection + down-projection + residual in one kernel
-        if fused == 2:
+        if fused == 3:      # LayerNorm folded: the kernel normalises the hi plane of the stream in registers, gamma / beta live in the pack
+            h = ops.ff_geglu320(h, d["s_ffp_ln"], d["s_f2b"], self._res(rows, C, dev), r1=h, ln_folded=True)
+        elif fused == 2:
             h = ops.ff_geglu320(h, d["s_ffp"], d["s_f2b"], self._res(rows, C, dev), r1=h, ln=(d["s_norm3g"], d["s_norm3b"]))
         elif fused:
             n3 = ops.layernorm(h, d["s_norm3g"], d["s_norm3b"])
@@ -572,7 +577,10 @@ class UNetSpatioTemporalConditionModel:
         hm = ops.linear(ao, d["t_ow"], d["t_ob"], out=Res.empty(rows, C, dev, False), rowbias=cv_t, rows_per_group=T * S,
                         ld_rowbias=self._cv_total, r1=hm, ld_r1=C)
         a = d["mix"]  # AlphaBlender: a*x_spatial + (1-a)*x_temporal, x_temporal = hm + ff(..); hb is only a GEMM operand
-        if fused == 2:
+        if fused == 3:
+            hb = ops.ff_geglu320(hm, d["t_ffp_ln"], d["t_f2b"], torch.empty(rows, C, dtype=torch.float16, device=dev), c_acc=1.0 - a, r1=hm,
+                                 c_r1=1.0 - a, r2=h, c_r2=a, ln_folded=True)
+        elif fused == 2:
             hb = ops.ff_geglu320(hm, d["t_ffp"], d["t_f2b"], torch.empty(rows, C, dtype=torch.float16, device=dev), c_acc=1.0 - a, r1=hm,
                                  c_r1=1.0 - a, r2=h, c_r2=a, ln=(d["t_norm3g"], d["t_norm3b"]))
         elif fused:

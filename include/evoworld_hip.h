@@ -27,7 +27,7 @@ typedef int ew_status;
 #define EW_ERR_UNSUPPORTED (-2)
 #define EW_ERR_HIP (-3)
 
-#define EW_ABI_VERSION 6
+#define EW_ABI_VERSION 7
 int ew_abi_version(void);
 const char* ew_last_error(void);
 
@@ -148,6 +148,12 @@ typedef struct ew_ff_args {
     const void* addvec;
     int add_rows_per_group;
     float ln_eps;
+    /* ABI 7 (round 4).  ln_folded != 0 (ln_gamma must be NULL): x is the hi plane of the stream; the kernel normalises every row to
+     * zero mean / unit variance (two-pass fp32 statistics over the fp16 values, eps = ln_eps) in registers, and the LayerNorm's affine
+     * part is expected FOLDED into the packs: W1 diag(gamma) and b1 + W1 beta (evoworld_amd.ops.ff_pack(..., ln=(gamma, beta))).  No
+     * operand loads in the prologue -- the per-tile gamma / beta / addvec loads are what made the ln_gamma form slower than a separate
+     * ew_layernorm_f16 launch. */
+    int ln_folded;
 } ew_ff_args;
 ew_status ew_ff_geglu320_f16(const ew_ff_args* args, void* stream);
 

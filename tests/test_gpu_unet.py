@@ -78,11 +78,12 @@ def test_unet_tiny_vs_oracle_fp32_weights():
     assert out[0] < TOL_FORWARD and out[1] < TOL_FORWARD_FP32_WEIGHTS
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_unet_level0_320_fused_feed_forward_modes(mode):
     """A shrunken config whose FIRST level has the real 320 channels (head_dim 64, hidden 1280), so that its three feed-forwards go through
     ew_ff_geglu320_f16: mode 0 = LayerNorm + two GEMMs, 1 = LayerNorm kernel + fused kernel (default), 2 = LayerNorm in the fused kernel's
-    prologue.  Every mode is checked against the fp32 oracle at the forward tolerance."""
+    prologue, 3 = norm3 folded into the up-projection of .ff (hi plane normalised in registers).  Every mode is checked against the fp32 oracle at the
+    forward tolerance."""
     from oracle.unet_ref import tiny_config
     cfg = tiny_config()
     cfg["block_out_channels"] = (320, 128, 256, 256)
