@@ -100,7 +100,8 @@ struct FfP {
 #define FF_ABL 0          /* ablation builds (tools/experiments): 1 no GEGLU math, 2 no DMA, 4 no epilogue, 8 no up-proj MFMA, 16 no down-proj MFMA */
 #endif
 
-template <bool LO, bool R2, int XLO>      // XLO: 0 = x as given (or the ln_gamma prologue on a plain fp16 x), 1 = ln_gamma prologue on hi + lo8, 2 = folded LayerNorm: normalise only
+template <bool LO, bool R2, int XLO>      // XLO: 0 = x as given, 1 = ln_gamma prologue on hi + lo8, 2 = folded LayerNorm (normalise only), 3 = ln_gamma prologue on a plain fp16 x
+                                          // (the prologue code is compiled into its own variants only: its presence alone cost the plain variants ~170 spilled VGPRs)
 __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -241,30 +242,50 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
     // Folded LayerNorm (XLO == 2, round 4): gamma / beta live in the packs (W1 diag(gamma), b1 + W1 beta), so the prologue is pure
     // register arithmetic on the fragments -- two-pass fp32 statistics over the row's 320 fp16 values (4 lanes x 80), normalise in place.
     auto norm_x = [&]() __attribute__((always_inline)) {
+        // Every pass re-converts from the packed fragments through an OPAQUE copy: left to itself hipcc converts the 160 values of a
+        // lane to fp32 once and keeps them across the three passes (160 more live registers -> ~150 scratch round trips per tile,
+        // each draining the weight-DMA queue: measured +0.38 ms per launch, profiles/r04_i_ff_folded_ln.txt).
+        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+        // (dword by dword: an inline-asm "+v" operand wider than 32 bits is mis-compiled by this hipcc -- all four lanes of the vector
+        // came back as its first dword)
+        auto opaque = [](const f16x8 x) __attribute__((always_inline)) {
+            u32x4v w = __builtin_bit_cast(u32x4v, x);
+            unsigned a = w[0], b = w[1], c = w[2], d = w[3];
+            asm volatile("" : "+v"(a));
+            asm volatile("" : "+v"(b));
+            asm volatile("" : "+v"(c));
+            asm volatile("" : "+v"(d));
+            return (u32x4v){a, b, c, d};
+        };
 #pragma unroll
         for (int rf = 0; rf < RF; ++rf) {
             float sum = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
+            for (int ks = 0; ks < KS; ++ks) {
+                const f16x8 v = __builtin_bit_cast(f16x8, opaque(xf[rf][ks]));
 #pragma unroll
-                for (int e = 0; e < 8; ++e) sum += (float)xf[rf][ks][e];
+                for (int e = 0; e < 8; ++e) sum += (float)v[e];
+            }
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
             const float mean = sum * (1.0f / C);
             float sq = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
+            for (int ks = 0; ks < KS; ++ks) {
+                const f16x8 v = __builtin_bit_cast(f16x8, opaque(xf[rf][ks]));
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = (float)xf[rf][ks][e] - mean; sq = fmaf(d, d, sq); }
+                for (int e = 0; e < 8; ++e) { const float d = (float)v[e] - mean; sq = fmaf(d, d, sq); }
+            }
             sq += __shfl_xor(sq, 16, 64);
             sq += __shfl_xor(sq, 32, 64);
             const float rstd = rsqrtf(sq * (1.0f / C) + p.ln_eps);
             const float nmr = -mean * rstd;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
+                const f16x8 v = __builtin_bit_cast(f16x8, opaque(xf[rf][ks]));
                 f16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (f16)fmaf((float)xf[rf][ks][e], rstd, nmr);
+                for (int e = 0; e < 8; ++e) o[e] = (f16)fmaf((float)v[e], rstd, nmr);
                 xf[rf][ks] = o;
             }
         }
@@ -275,7 +296,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
     for (int ti = 0; ti < n_my; ++ti) {
         const int tile = (int)blockIdx.x + ti * G;
         const int m_w0 = tile * BM + wm * WROWS;
-        if constexpr (XLO == 2) norm_x(); else if (p.ln_gamma) ln_x(tile);
+        if constexpr (XLO == 2) norm_x(); else if constexpr (XLO == 1 || XLO == 3) ln_x(tile);
         f32x4 acc2[RF][NJ2];
 #pragma unroll
         for (int rf = 0; rf < RF; ++rf)
@@ -586,6 +607,7 @@ extern "C" ew_status ew_ff_geglu320_f16(const ew_ff_args* a, void* stream) {
         else FF_LAUNCH(true, false, 2);
     }
     else if (lo && r2 && xlo) FF_LAUNCH(true, true, 1);
+    else if (a->ln_gamma && !xlo) FF_LAUNCH(true, true, 3);          // ln_gamma prologue on a plain fp16 x: one superset variant
     else if (lo && r2) FF_LAUNCH(true, true, 0);
     else if (lo && xlo) FF_LAUNCH(true, false, 1);
     else if (lo) FF_LAUNCH(true, false, 0);
