@@ -11,11 +11,12 @@
 // written and read back 15 times per forward and the normalised tensor 15 times more.  Here neither leaves the chip:
 //   * one workgroup = 8 waves as 4 (M) x 2 (N), two per SIMD, on a 128-row tile.  A wave owns 32 rows; their (normalised) x
 //     fragments stay in 80 registers for the whole tile.  The LayerNorm runs on those registers (prologue).  Register
-//     budget as compiled (-Rpass-analysis=kernel-resource-usage, round 4): 256 VGPRs, 0 AGPRs, 197-224 spilled VGPRs
-//     (792-864 B of scratch per lane; ~400 with the LayerNorm prologue) -- every scratch access sits in the per-TILE
-//     prologue / epilogue (x-fragment load, direct epilogue: 174 + 11 scratch instructions per tile against 2400 MFMAs);
-//     the 40-iteration chunk loop itself holds x fragments, both accumulator sets and the W fragments in registers with
-//     zero scratch traffic (checked in the ISA: no scratch_load / scratch_store between the loop header and its back edge);
+//     budget as compiled (-Rpass-analysis=kernel-resource-usage, round 4): 256 VGPRs, 0 AGPRs, 17-55 spilled VGPRs in the
+//     plain variants (72-224 B of scratch per lane; the ln_gamma prologue variants 171-446, the folded-LayerNorm ones 34-58) --
+//     every scratch access sits in the per-TILE prologue / epilogue; the 40-iteration chunk loop itself holds x fragments, both
+//     accumulator sets and the W fragments in registers with zero scratch traffic (checked in the ISA: no scratch_load /
+//     scratch_store between the loop header and its back edge).  (Until round 4 the ln_gamma prologue was a run-time branch
+//     inside every variant: dead code in the shipped configuration, but it cost the plain variants ~170 more spilled VGPRs.);
 //   * the hidden dimension is walked in 40 chunks of 32.  Up-projection of a chunk: the wave computes the value + gate columns
 //     of ITS half of the chunk (16 hidden units: 2 fragments x 2 row fragments x 10 k-steps = 40 MFMAs), applies bias and
 //     value * gelu(gate) in registers and leaves its four halves per lane in a small LDS exchange buffer; after the chunk's
