@@ -51,7 +51,7 @@ if w["ln_kernel_1_4"]:
 sys.path.insert(0, repo)
 import bench
 out = {"recorded_at": {"source_fingerprint": bench.source_fingerprint(), "residual_stream": os.environ.get("EW_RESIDUAL", "split"),
-                       "round": 3},
+                       "round": 4},
        "bytes_per_forward": read_b + write_b, "read_bytes_per_forward": read_b, "written_bytes_per_forward": write_b,
        "fetch_correction": 2.0, "write_correction": 1.0, "calibration_on_ln_kernel": cal,
        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 1 --warmup 0 --denoise-steps 1 (two forwards); tools/pmc_traffic.sh"}
