@@ -53,7 +53,10 @@ constexpr int W1_TILE = KT * W1_KT;                                // 40 KB per 
 constexpr int W2_TILE = C * CH * 2;                                // 320 staged rows x 32 k x 2 B = 20 KB per chunk
 constexpr int HX_TILE = (BM / 16) * 64 * 16;                       // GEGLU exchange: 8 row fragments x 64 lanes x 16 B = 8 KB per chunk
 constexpr int LDS_W1 = 0, LDS_W2 = 2 * W1_TILE, LDS_HX = LDS_W2 + 2 * W2_TILE, LDS_B1 = LDS_HX + 2 * HX_TILE;
-constexpr int LDS_SCR = LDS_B1 + 2 * HID * 2;                     // 4 KB scratch slot (FF_GSHADOW: GEGLU output of the no-op first slice)
+#ifndef FF_BIAS_C
+#define FF_BIAS_C 1       /* 1 (round 4): b1 sits in LDS as fp32 and enters through the C operand of a chunk's first up-projection MFMAs (no cvt / add in the GEGLU) */
+#endif
+constexpr int LDS_SCR = LDS_B1 + 2 * HID * (FF_BIAS_C ? 4 : 2);   // 4 KB scratch slot (FF_GSHADOW: GEGLU output of the no-op first slice)
 constexpr int LDS_BYTES = LDS_SCR + 64 * NWV * 8 + 4096;                    // 80 + 40 + 16 + 5 KB
 constexpr int P1 = W1_TILE / 1024 / NWV;                           // W1 DMA pieces per wave and chunk (5); W2's 20 pieces are dealt round-robin
 constexpr int P2MAX = (W2_TILE / 1024 + NWV - 1) / NWV;            // 3 (waves 4-7 issue 2)
@@ -115,7 +118,15 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
     // fragment (no branch in the pipeline), which must not meet NaN bit patterns of uninitialised LDS
     for (int i = tid; i < (2 * W2_TILE + 2 * HX_TILE) / 16; i += 64 * NWV) *(f16x8*)(smem + LDS_W2 + i * 16) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
     // packed b1 -> LDS once (5 KB)
+#if FF_BIAS_C
+    for (int i = tid; i < 2 * HID / 8; i += 64 * NWV) {
+        const f16x8 b = *(const f16x8*)((const char*)p.b1p + i * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ((float*)(smem + LDS_B1))[i * 8 + e] = (float)b[e];
+    }
+#else
     for (int i = tid; i < 2 * HID * 2 / 16; i += 64 * NWV) *(f16x8*)(smem + LDS_B1 + i * 16) = *(const f16x8*)((const char*)p.b1p + i * 16);
+#endif
 
     const int G = gridDim.x;
     const int n_my = (p.n_tiles - (int)blockIdx.x + G - 1) / G;            // tiles blockIdx.x, +G, ...
@@ -320,9 +331,13 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
         // halves (ping-pong, two barriers per chunk) measured 12 % slower, scalar instead of packed fp32 GEGLU 3 % slower.
         // bias + GEGLU of one row fragment of this wave's half chunk: fragments (value 2 wn, gate 2 wn + 1) -> hidden 8 fks + 4 wn + e
         auto geglu_rf = [&](const f32x4 (&a)[2], const char* bb, char* dst) __attribute__((always_inline)) {
+#if FF_BIAS_C
+            const f32x4 va = a[0], gg = a[1];          // the bias came in through the accumulators' initial value
+#else
             const f16x4 bv = *(const f16x4*)bb, bg = *(const f16x4*)(bb + 32);
             const f32x4 va = a[0] + (f32x4){(float)bv[0], (float)bv[1], (float)bv[2], (float)bv[3]};
             const f32x4 gg = a[1] + (f32x4){(float)bg[0], (float)bg[1], (float)bg[2], (float)bg[3]};
+#endif
 #if FF_ABL & 1
             const f32x2 o01 = (f32x2){va[0], va[1]} * (f32x2){gg[0], gg[1]};
             const f32x2 o23 = (f32x2){va[2], va[3]} * (f32x2){gg[2], gg[3]};
@@ -338,10 +353,19 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
             const char* w1n = smem + LDS_W1 + ((cc + 1) & 1) * W1_TILE;
             const char* w2b = smem + LDS_W2 + ((cc + 1) & 1) * W2_TILE;       // W2(cc - 1)
             f32x4 acc1[RF][2];
+#if FF_BIAS_C
+            {   // this chunk's bias (value fragment, gate fragment: 4 consecutive hidden units of this lane each) = the C operand
+                const char* bc = smem + LDS_B1 + (c * 64 + 2 * wn * 16 + fks * 4) * 4;
+                const f32x4 b0 = *(const f32x4*)bc, b1v = *(const f32x4*)(bc + 64);
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf) { acc1[rf][0] = b0; acc1[rf][1] = b1v; }
+            }
+#else
 #pragma unroll
             for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc1[rf][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
             FF_STAMP(0);
             // FF_GSHADOW: the GEGLU of the PREVIOUS chunk (VALU, ~90 instructions with two transcendentals per element) is issued between
             // the up-projection MFMAs of this one, one row fragment per half of the k loop; its halves go to exchange buffer (cc - 1) & 1 and are
