@@ -279,10 +279,37 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     }
 
     f32x4 acc[FM][FN];
+#ifndef EW_G3_BIAS_INIT
+#define EW_G3_BIAS_INIT 1       /* 1 (round 4): the bias vector is the accumulators' initial value (10 8-byte loads + 40 cvt per work item) instead of
+                                   one cvt + add per output element in every epilogue step */
+#endif
+    // Accumulators of a work item start as the bias of its tile column (every row fragment the same 4 columns per lane and
+    // fragment), or as zeros for the TAIL of a stream-K tile (k0 > 0: another block owns the head, and the bias with it).
+    auto init_acc = [&](const int id, const int k0) __attribute__((always_inline)) {
+#if EW_G3_BIAS_INIT
+        int tm, tn;
+        tile_coords(id, p.tiles_m, p.tiles_n, p.band, tm, tn);
+        int lane_o = tid & 63;                       // opaque copy: keeps the bias addresses out of the main loop's live set
+        asm volatile("" : "+v"(lane_o));
+        const int fks_o = lane_o >> 4;
+        const f16* bsrc = (p.bias && k0 == 0) ? p.bias + tn * BN + wn * WN + (DIRECT ? fks_o * 8 : fks_o * 4) : p.zero_page;
+        const int on = (p.bias && k0 == 0) ? 1 : 0;
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+        for (int j = 0; j < FN; ++j) {
+            // DIRECT (permuted W staging): fragment j, element e <-> column (j >> 1) * 32 + fks * 8 + (j & 1) * 4 + e; otherwise j * 16 + fks * 4 + e
+            const int col = DIRECT ? (j >> 1) * 32 + (j & 1) * 4 : j * 16;
+            const f16x4 b4 = *(const f16x4*)(bsrc + col * on);
+            const f32x4 b = {(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < FM; ++i) acc[i][j] = b;
+        }
+#else
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
+    };
     f16x8 af[2][FM];                       // A fragments of the two k-halves
     f16x8 bfr[4];                          // W fragment ring: step t consumes bfr[t & 3]
 
@@ -303,6 +330,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     int cur_w = 0, cur_id, cur_kt, cur_k1;
     EW3_GET_ITEM(0, cur_id, cur_kt, cur_k1);
     cur_w = 1;
+    init_acc(cur_id, cur_kt);
     bool cur_tail = cur_kt > 0;                      // stream-K: this item is the tail of a tile another block finishes
     int s_cur = 0;                                   // ring slot of stream position v
     for (int v = 0; v < V; ++v) {
@@ -409,8 +437,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                             for (int jj = 0; jj < CP / 16; ++jj) {
                                 const int j = h * (CP / 16) + jj;
                                 const int n = n_w0 + j * 16 + fks * 4;
+#if EW_G3_BIAS_INIT
+                                f32x4 x = acc[i][j];
+#else
                                 const f16x4 b4 = *(const f16x4*)((const char*)bp + (unsigned)(n * mbias) * 2u);
                                 f32x4 x = acc[i][j] + (f32x4){(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
+#endif
                                 if constexpr (RB) {
                                     const f16x4 r4 = *(const f16x4*)((const char*)rbp + (unsigned)(g * ldrb + n * mrb) * 2u);
                                     x += (f32x4){(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
@@ -463,7 +495,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                         const int m = m_w0 + i * 16 + rowv[it], n = n_w0 + h * CP + c8v[it];
                         const int mc = FULL ? m : min(m, p.M - 1);
                         // uniform base + 32-bit byte offset (every operand of this path is < 4 GB): one VGPR per address
+#if !EW_G3_BIAS_INIT
                         bvv = *(const f16x8*)((const char*)bp + (unsigned)(n * mbias) * 2u);
+#endif
                         if constexpr (RB) {
                             const int g = rpg >= WM ? g0 + (mc >= gbound ? 1 : 0) : mc / rpg;
                             rbv = *(const f16x8*)((const char*)rbp + (unsigned)(g * ldrb + n * mrb) * 2u);
@@ -491,7 +525,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                                 f16x8 o;
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) {
+#if !EW_G3_BIAS_INIT
                                     vv[e] += (float)bvv[e];
+#endif
                                     if constexpr (RB) vv[e] += (float)rbv[e];
                                 }
                                 if (p.act == EW_ACT_SILU) {
@@ -538,7 +574,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                         const int m = m_w0 + i * 16 + frow, n = ncol0 + q * 32;
                         const int mc = FULL ? m : min(m, p.M - 1);
                         // uniform base + 32-bit byte offset (every operand of this path is < 4 GB): one VGPR per address
+#if !EW_G3_BIAS_INIT
                         bvv = *(const f16x8*)((const char*)bp + (unsigned)(n * mbias) * 2u);
+#endif
                         if constexpr (RB) {
                             const int g = rpg >= WM ? g0 + (mc >= gbound ? 1 : 0) : mc / rpg;
                             rbv = *(const f16x8*)((const char*)rbp + (unsigned)(g * ldrb + n * mrb) * 2u);
@@ -562,7 +600,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                             int s8[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
+#if !EW_G3_BIAS_INIT
                                 vv[e] += (float)bvv[e];
+#endif
                                 if constexpr (RB) vv[e] += (float)rbv[e];
                             }
                             if (silu) {
@@ -601,8 +641,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                     f32x4 bq[FN];
 #pragma unroll
                     for (int j = 0; j < FN; ++j) {
+#if EW_G3_BIAS_INIT
+                        bq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#else
                         const f16x4 b4 = *(const f16x4*)(bp + (n_w0 + j * 16 + fks * 4) * mbias);
                         bq[j] = (f32x4){(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
+#endif
                     }
 #pragma unroll
                     for (int i = 0; i < FM; ++i) {
@@ -713,10 +757,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
             }
             // Every path above only READS the accumulators; they are cleared here, once, for the next work item (clearing them
             // inside each path gave the allocator a three-way merge of 160 registers: copies and ~280 spilled VGPRs).
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            init_acc(cur_id, cur_kt);            // (cur_* already describe the NEXT item; past the last one the values are never used)
             // first fragments of the next tile's first K-tile (skipped at steps 18-19 of this position)
             {
                 const char* c2 = smem + s_cur * STAGE;
