@@ -426,7 +426,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                     constexpr int LDH = CP + 8;              // patch row stride in halfs (176 B)
                     f16* patch16 = (f16*)patch;
                     const int rpg = p.rows_per_group;
-                    const bool silu = p.act == EW_ACT_SILU, gelu = MODE == EW_A_DENSE && EPI == 0 && p.act == EW_ACT_GELU;
+                    // SiLU / GELU are compiled into the plain dense variants only (the U-Net's SiLU GEMMs have M = 2 ... 25 and run on generation 2,
+                    // GELU is CLIP's fc1): in every other variant the dead activation block was ~100 instructions and 3 branches per epilogue step
+                    constexpr bool ACT_OK = MODE == EW_A_DENSE && (EPI & ~1) == 0;
+                    const bool silu = ACT_OK && p.act == EW_ACT_SILU, gelu = ACT_OK && EPI == 0 && p.act == EW_ACT_GELU;
 #pragma unroll
                     for (int i = 0; i < FM; ++i) {
                         const int m_l = min(m_w0 + i * 16 + frow, p.M - 1);
@@ -530,10 +533,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
 #endif
                                     if constexpr (RB) vv[e] += (float)rbv[e];
                                 }
-                                if (p.act == EW_ACT_SILU) {
-#pragma unroll
-                                    for (int e = 0; e < 8; ++e) vv[e] = ew_silu(vv[e]);
-                                }
+                                // (no activation in this path: SiLU / GELU problems with residual operands or conv modes run on generation 2)
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) {
                                     float x = vv[e] * p.c_acc;
@@ -586,7 +586,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                         if constexpr (R1 && LO) q1l = *(const u32x2*)((const char*)r1lp + (unsigned)(mc * ld1l + n * m1l));
                         if constexpr (R2 && LO) q2l = *(const u32x2*)((const char*)r2lp + (unsigned)(mc * ld2l + n * m2l));
                     };
-                    const bool silu = p.act == EW_ACT_SILU, gelu = MODE == EW_A_DENSE && EPI == 0 && p.act == EW_ACT_GELU;
+                    // SiLU / GELU are compiled into the plain dense variants only (the U-Net's SiLU GEMMs have M = 2 ... 25 and run on generation 2,
+                    // GELU is CLIP's fc1): in every other variant the dead activation block was ~100 instructions and 3 branches per epilogue step
+                    constexpr bool ACT_OK = MODE == EW_A_DENSE && (EPI & ~1) == 0;
+                    const bool silu = ACT_OK && p.act == EW_ACT_SILU, gelu = ACT_OK && EPI == 0 && p.act == EW_ACT_GELU;
                     fetch(0, 0);
 #pragma unroll
                     for (int i = 0; i < FM; ++i) {
@@ -957,6 +960,7 @@ bool EW3_NAME(ew_gemm3_wants)(const GemmP& p) {
     // GELU (CLIP's fc1) is only compiled into the plain dense variant: the erf code in every epilogue cost the conv variants
     // 11-28 spilled VGPRs (reloads inside the K loop, 4-10 % slower); anything else with GELU runs on generation 2
     if (p.act == EW_ACT_GELU && (p.mode != EW_A_DENSE || p.rowbias || p.r1 || p.r2 || p.out_lo)) return false;
+    if (p.act == EW_ACT_SILU && (p.mode != EW_A_DENSE || p.r1 || p.r2 || p.r1_lo || p.r2_lo || p.out_lo)) return false;      // same for SiLU (round 4)
     // the epilogue addresses its row operands as uniform base + 32-bit byte offset
     const long long ld_max = max((long long)p.ld_out, max((long long)p.ld_r1, (long long)p.ld_r2));
     if ((long long)p.M * ld_max * 2 >= (1LL << 32)) return false;
