@@ -113,6 +113,12 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int frow = lane & 15, fks = lane >> 4, sw = frow & 7;
+#ifndef EW_PRIO_YOUNG
+#define EW_PRIO_YOUNG 1       /* A/B (round 4: -0.3 ... -0.7 ms per forward each, profiles/r04_l_static_prio.txt): static s_setprio 1 for the second-dispatched half of the workgroup (MI355X_MICROARCH, two waves per SIMD, item 4) */
+#endif
+#if EW_PRIO_YOUNG
+    if (wave >= NWV / 2) __builtin_amdgcn_s_setprio(1);
+#endif
 
     // W2 and exchange buffers start as zeros: the first chunk of a tile runs the trailing down-projection slot on a zero A
     // fragment (no branch in the pipeline), which must not meet NaN bit patterns of uninitialised LDS

@@ -91,6 +91,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+#ifndef EW_PRIO_YOUNG
+#define EW_PRIO_YOUNG 1       /* A/B (round 4: -0.3 ... -0.7 ms per forward each, profiles/r04_l_static_prio.txt): static s_setprio 1 for the second-dispatched half of the workgroup */
+#endif
+#if EW_PRIO_YOUNG
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
 
     // ---- tile sequence of this persistent block: step i -> tile id i*G + (b%8)*(G/8) + b/8  (XCD-contiguous chunks)
     const int G = gridDim.x;
