@@ -25,6 +25,9 @@
 #ifndef EW_ATTN_SCALAR_FMA
 #define EW_ATTN_SCALAR_FMA 1
 #endif
+#ifndef EW_ATTN_PRIO
+#define EW_ATTN_PRIO 0       /* A/B: 1 = s_setprio 1 around the QK^T MFMA cluster, 2 = around the P.V cluster too */
+#endif
 #ifndef EW_ATTN_ROWSUM
 #define EW_ATTN_ROWSUM 0     /* 0: v_dot2c of the fp16-rounded P (round-toward-zero pack); 1: f32 adds of the exponentials + round-to-nearest pack (A/B, round 4) */
 #endif
@@ -153,6 +156,9 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
         }
 
         // ---- S^T = K Q^T : two 32-key blocks ----
+#if EW_ATTN_PRIO
+        __builtin_amdgcn_s_setprio(1);      // A/B (round 4, guide T5): favour the wave that is entering an MFMA cluster
+#endif
         f32x16 sacc[2];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
@@ -168,6 +174,9 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
                 sacc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[blk], 0, 0, 0);
             }
         }
+#if EW_ATTN_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- mask the ragged last tile ----
         if (key0 + 64 > S) {
 #pragma unroll
@@ -257,6 +266,9 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
                 pf[blk * 2 + g2] = __builtin_bit_cast(f16x8, wv);
             }
         // ---- O^T += V^T P^T ----
+#if EW_ATTN_PRIO == 2
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int g = 0; g < 4; ++g) {       // 16-key group (MFMA k-step)
 #pragma unroll
@@ -265,6 +277,9 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
                 oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[g], oacc[db], 0, 0, 0);
             }
         }
+#if EW_ATTN_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // double-buffered tiles: the other buffer was last read in iteration j-1 (every wave passed that barrier)
         if (j + 1 < nt) write_tile(std::integral_constant<int, BUF ^ 1>{});
         __syncthreads();
