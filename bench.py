@@ -245,7 +245,7 @@ def main():
     # --gpus N from a plain `python bench.py`: re-exec as N ranks (one process per GPU) under torch.distributed.run
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and os.environ.get("EW_SHARE_GPU") != "1":
             raise SystemExit(f"--gpus {args.gpus} but only {have} device(s) answer")
         import socket
         import subprocess
@@ -264,6 +264,8 @@ def main():
     rank, world, local = D.init()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    if os.environ.get("EW_SHARE_GPU") == "1":          # test hook: every rank on the visible devices round-robin (with EW_DIST_BACKEND=gloo)
+        local = local % torch.cuda.device_count()
     if torch.cuda.device_count() <= local:
         raise SystemExit(f"rank {rank}: local device {local} does not exist ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local)
@@ -341,6 +343,10 @@ def main():
     dt = D.max_over_ranks(dt, dev)
     unet.forward_nhwc = orig_forward
     finite = all(bool(torch.isfinite(r).all()) for r in res)
+    if args.split == "cfg" and world > 1:              # both members of a CFG pair hold the whole clip: they must agree bit for bit
+        for q in range(0, world, 2):
+            if not torch.equal(res[q], res[q + 1]):
+                raise SystemExit(f"CFG pair {q // 2}: the two members returned different latents")
     from evoworld_amd import ops as _ops
     _ops.streamk_check()                      # (pipe.denoise already checked after every clip; this covers the hooked forward too)
 

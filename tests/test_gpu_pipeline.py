@@ -217,6 +217,25 @@ def test_bench_cfg_split_one_rank_over_rccl():
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["parallelism"] == "cfg1 x dp1" and line["scaling"] == "weak"
 
 
+@pytest.mark.parametrize("split", ["clip", "cfg"])
+def test_bench_two_ranks_on_one_gpu_over_gloo(split):
+    """The N = 2 control flow end to end on a one-GPU box: bench.py --gpus 2 spawns two ranks under torch.distributed.run, both on
+    cuda:0 (EW_SHARE_GPU=1) with the gloo backend (RCCL refuses two ranks on one device): rank-0 weights -> broadcast -> checksum on
+    both ranks; clip sharding + gather, or (--split cfg) one CFG row per rank with the per-step eps all_gather between REAL forwards."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "EW_FORCE_DIST")}
+    env.update(EW_SHARE_GPU="1", EW_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--tiny", "--steps", "1", "--warmup", "0", "--denoise-steps", "2",
+                        "--height", "128", "--width", "256", "--no-cpu-baseline", "--split", split], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "weight broadcast to 2 rank(s)" in r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["config"]["parallelism"] == ("dp2" if split == "clip" else "cfg2 x dp1")
+    assert line["scaling"] == ("weak" if split == "clip" else "strong")
+
+
 @pytest.mark.skipif(not __import__("os").environ.get("EW_FULL_PARITY_STEPS"),
                     reason="full-size clip against the fp32 CPU oracle: ~3 min of host time per denoise step; EW_FULL_PARITY_STEPS=25 "
                            "(result committed under profiles/)")
