@@ -570,13 +570,23 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                     constexpr int NQ = FN / 2;                  // 5 fragment pairs = 5 x 32 columns per wave tile
                     // vmcnt is in-order: a load issued after a store cannot be waited for without draining that store, so the
                     // operands of step s+1 are requested BEFORE the store of step s -- but after step s has consumed its own.
-                    f16x8 bvv, rbv, q1v, q2v;
-                    u32x2 q1l, q2l;
+#ifndef EW_G3_EPI_DEPTH
+#define EW_G3_EPI_DEPTH 2       /* epilogue steps whose operand loads are in flight (operand register sets).  Round 4 A/B (profiles/r04_o_epilogue_depth.txt):
+                                   2 buys 2-7 % on the short-K residual GEMMs now that the bias / activation code is out of the steps (it only spilled in
+                                   round 2); 3 spills in the conv + row-bias variants (+10 %); <0,23> (two split residuals) loses at 2 already */
+#endif
+                    constexpr int ED = (EPI == 23) ? 1 : ((R1 || R2 || RB) ? EW_G3_EPI_DEPTH : 1);
+                    f16x8 rbv[ED], q1v[ED], q2v[ED];
+                    u32x2 q1l[ED], q2l[ED];
+#if !EW_G3_BIAS_INIT
+                    f16x8 bvv;
+#endif
                     const int rpg = p.rows_per_group;
                     const int g0 = min(m_w0, p.M - 1) / rpg;             // wave tiles past the last row must not index a group beyond the last
                     const int gbound = rpg >= WM ? (g0 + 1) * rpg : 0x7fffffff;
                     const int ncol0 = n_w0 + fks * 8;
-                    auto fetch = [&](int i, int q) {
+                    auto fetch = [&](const int k) __attribute__((always_inline)) {       // step k = i * NQ + q -> operand set k % ED
+                        const int i = k / NQ, q = k - i * NQ, st = k % ED;
                         const int m = m_w0 + i * 16 + frow, n = ncol0 + q * 32;
                         const int mc = FULL ? m : min(m, p.M - 1);
                         // uniform base + 32-bit byte offset (every operand of this path is < 4 GB): one VGPR per address
@@ -585,22 +595,23 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
 #endif
                         if constexpr (RB) {
                             const int g = rpg >= WM ? g0 + (mc >= gbound ? 1 : 0) : mc / rpg;
-                            rbv = *(const f16x8*)((const char*)rbp + (unsigned)(g * ldrb + n * mrb) * 2u);
+                            rbv[st] = *(const f16x8*)((const char*)rbp + (unsigned)(g * ldrb + n * mrb) * 2u);
                         }
-                        if constexpr (R1) q1v = *(const f16x8*)((const char*)r1p + (unsigned)(mc * ld1 + n * m1) * 2u);
-                        if constexpr (R2) q2v = *(const f16x8*)((const char*)r2p + (unsigned)(mc * ld2 + n * m2) * 2u);
-                        if constexpr (R1 && LO) q1l = *(const u32x2*)((const char*)r1lp + (unsigned)(mc * ld1l + n * m1l));
-                        if constexpr (R2 && LO) q2l = *(const u32x2*)((const char*)r2lp + (unsigned)(mc * ld2l + n * m2l));
+                        if constexpr (R1) q1v[st] = *(const f16x8*)((const char*)r1p + (unsigned)(mc * ld1 + n * m1) * 2u);
+                        if constexpr (R2) q2v[st] = *(const f16x8*)((const char*)r2p + (unsigned)(mc * ld2 + n * m2) * 2u);
+                        if constexpr (R1 && LO) q1l[st] = *(const u32x2*)((const char*)r1lp + (unsigned)(mc * ld1l + n * m1l));
+                        if constexpr (R2 && LO) q2l[st] = *(const u32x2*)((const char*)r2lp + (unsigned)(mc * ld2l + n * m2l));
                     };
                     // SiLU / GELU are compiled into the plain dense variants only (the U-Net's SiLU GEMMs have M = 2 ... 25 and run on generation 2,
                     // GELU is CLIP's fc1): in every other variant the dead activation block was ~100 instructions and 3 branches per epilogue step
                     constexpr bool ACT_OK = MODE == EW_A_DENSE && (EPI & ~1) == 0;
                     const bool silu = ACT_OK && p.act == EW_ACT_SILU, gelu = ACT_OK && EPI == 0 && p.act == EW_ACT_GELU;
-                    fetch(0, 0);
 #pragma unroll
-                    for (int i = 0; i < FM; ++i) {
+                    for (int k = 0; k < ED; ++k) fetch(k);
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) {
+                    for (int k = 0; k < FM * NQ; ++k) {
+                        {
+                            const int i = k / NQ, q = k - i * NQ, st = k % ED;
                             const int m = m_w0 + i * 16 + frow, n = ncol0 + q * 32;
                             const f32x4 a0 = acc[i][2 * q], a1 = acc[i][2 * q + 1];
                             float vv[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
@@ -612,7 +623,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
 #if !EW_G3_BIAS_INIT
                                 vv[e] += (float)bvv[e];
 #endif
-                                if constexpr (RB) vv[e] += (float)rbv[e];
+                                if constexpr (RB) vv[e] += (float)rbv[st][e];
                             }
                             if (silu) {
 #pragma unroll
@@ -624,17 +635,16 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
                                 float x = vv[e] * p.c_acc;
-                                if constexpr (R1 && LO) x += p.c_r1 * ew_split_dec(q1v[e], ew_sbyte(q1l[e >> 2], e & 3));
-                                else if constexpr (R1) x += p.c_r1 * (float)q1v[e];
-                                if constexpr (R2 && LO) x += p.c_r2 * ew_split_dec(q2v[e], ew_sbyte(q2l[e >> 2], e & 3));
-                                else if constexpr (R2) x += p.c_r2 * (float)q2v[e];
+                                if constexpr (R1 && LO) x += p.c_r1 * ew_split_dec(q1v[st][e], ew_sbyte(q1l[st][e >> 2], e & 3));
+                                else if constexpr (R1) x += p.c_r1 * (float)q1v[st][e];
+                                if constexpr (R2 && LO) x += p.c_r2 * ew_split_dec(q2v[st][e], ew_sbyte(q2l[st][e >> 2], e & 3));
+                                else if constexpr (R2) x += p.c_r2 * (float)q2v[st][e];
                                 o[e] = (f16)x;
                                 if constexpr (LO) s8[e] = ew_split_enc(x, o[e]);
                             }
                             if constexpr (LO) { ol[0] = ew_pack4(s8[0], s8[1], s8[2], s8[3]); ol[1] = ew_pack4(s8[4], s8[5], s8[6], s8[7]); }
                             __builtin_amdgcn_sched_barrier(0);
-                            if (q + 1 < NQ) fetch(i, q + 1);
-                            else if (i + 1 < FM) fetch(i + 1, 0);
+                            if (k + ED < FM * NQ) fetch(k + ED);
                             __builtin_amdgcn_sched_barrier(0);
                             if ((FULL || m < p.M) && !(p.dbg & 1)) {
                                 *(f16x8*)((char*)p.out + (unsigned)(m * p.ld_out + n) * 2u) = o;
