@@ -87,6 +87,23 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     // epilogue family: GEGLU (EPI & 8) and the conv modes without lo8 operands go through a wave-private LDS patch; dense GEMMs
     // and everything that carries the split residual stream use the LDS-free direct epilogue (permuted W staging)
     constexpr bool DIRECT = (EPI & 8) == 0 && (MODE == EW_A_DENSE || (EPI & 16));
+#ifndef EW_G3_BIAS_INIT
+#define EW_G3_BIAS_INIT 1       /* 1 (round 4): the bias vector is the accumulators' initial value (10 8-byte loads + 40 cvt per work item) instead of
+                                   one cvt + add per output element in every epilogue step */
+#endif
+#ifndef EW_G3_RB_INIT
+#define EW_G3_RB_INIT 1         /* round 5: in the DIRECT variants the row-bias (one vector per row group) enters through the accumulators' INITIAL
+                                   value, next to the bias (init_acc: 40 8-byte loads of L2-resident rows per work item) -- the epilogue steps lose a
+                                   16-byte operand load, 16 VALU and the per-step row-group computation (an integer division) */
+#endif
+#ifndef EW_G3_RESLDS
+#define EW_G3_RESLDS 1          /* round 5: residual operands of the DIRECT epilogue come in through the LDS (see the RES_LDS epilogue below) */
+#endif
+    constexpr bool RB_INIT = bool(EW_G3_RB_INIT) && bool(EW_G3_BIAS_INIT) && DIRECT && (EPI & 1);
+    // DIRECT variants with residual operands: the epilogue takes both LDS stages as landing zones of its residual tiles (LDS-DMA, 8 KB per
+    // wave, operand and row fragment: 60-120 KB in flight per CU instead of the ~24 KB two VGPR operand sets allowed), so the first
+    // K-tile of the NEXT work item is not prefetched during the last K-tile of this one but staged inside the epilogue.
+    constexpr bool RES_LDS = bool(EW_G3_RESLDS) && bool(EW_G3_RB_INIT) && bool(EW_G3_BIAS_INIT) && DIRECT && (EPI & 6) != 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -285,10 +302,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     }
 
     f32x4 acc[FM][FN];
-#ifndef EW_G3_BIAS_INIT
-#define EW_G3_BIAS_INIT 1       /* 1 (round 4): the bias vector is the accumulators' initial value (10 8-byte loads + 40 cvt per work item) instead of
-                                   one cvt + add per output element in every epilogue step */
-#endif
     // Accumulators of a work item start as the bias of its tile column (every row fragment the same 4 columns per lane and
     // fragment), or as zeros for the TAIL of a stream-K tile (k0 > 0: another block owns the head, and the bias with it).
     auto init_acc = [&](const int id, const int k0) __attribute__((always_inline)) {
@@ -308,6 +321,23 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
             const f32x4 b = {(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
 #pragma unroll
             for (int i = 0; i < FM; ++i) acc[i][j] = b;
+        }
+        if constexpr (RB_INIT) {
+            // + row-bias of the row group of each of the lane's FM rows (same 4 / 8 consecutive columns as the bias above)
+            const int frow_o = lane_o & 15;
+            const int onr = (p.rowbias && k0 == 0) ? 1 : 0;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int row = min(tm * BM + wm * WM + i * 16 + frow_o, p.M - 1);
+                const int g = row / p.rows_per_group;
+                const f16* rsrc = onr ? p.rowbias + (size_t)g * p.ld_rowbias + tn * BN + wn * WN + fks_o * 8 : p.zero_page;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int col = (j >> 1) * 32 + (j & 1) * 4;
+                    const f16x4 r4 = *(const f16x4*)(rsrc + col * onr);
+                    acc[i][j] += (f32x4){(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
+                }
+            }
         }
 #else
 #pragma unroll
@@ -344,7 +374,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
         char* nxt = smem + (s_cur ^ 1) * STAGE;
         const bool tile_end = cur_kt == cur_k1 - 1;
         const bool pend = staged < V;                // K-tile v+1 exists: stage it into the other slot during steps 0..8
-        if (pend) { stage_begin(nxt); ++staged; }
+        // RES_LDS: at a tile end both stages belong to the epilogue's residual tiles; K-tile v+1 (the first of the next work item)
+        // is staged inside the epilogue instead (tile-end section below)
+        const bool pend_now = pend && !(RES_LDS && tile_end);
+        if (pend_now) { stage_begin(nxt); ++staged; }
 #pragma unroll
         for (int t = 0; t < NSTEP; ++t) {
             const int kh = t / FN, j = t - kh * FN;
@@ -367,7 +400,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                 }
             }
             if (t < NP) {
-                if (pend) stage_piece(t);
+                if (pend_now) stage_piece(t);
             }
             EW3_PIN();
 #pragma unroll
@@ -562,7 +595,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                     // fragments (2q, 2q+1) of a lane are 8 consecutive output columns of row frow -> every operand access
                     // (bias, row-bias, residuals and their lo halves, output hi / lo) is ONE 16-byte access per lane, four
                     // lanes cover a 64-byte row segment, a wave instruction covers 16 rows x 64 B.
-                    constexpr bool RB = EPI & 1, R1 = EPI & 2, R2 = EPI & 4, LO = EPI & 16;
+                    constexpr bool RB = (EPI & 1) && !RB_INIT, R1 = EPI & 2, R2 = EPI & 4, LO = EPI & 16;      // (RB_INIT: the row-bias is already in the accumulators)
                     const int8_t* r1lp = p.r1_lo ? p.r1_lo : (const int8_t*)p.zero_page;      // lo8 companions (common.h): 1 byte / element
                     const int8_t* r2lp = p.r2_lo ? p.r2_lo : (const int8_t*)p.zero_page;
                     const int m1l = p.r1_lo ? 1 : 0, m2l = p.r2_lo ? 1 : 0;
@@ -698,6 +731,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                     }
                 }
             };
+            bool res_run = false;                    // RES_LDS: run the epilogue below (not a stream-K contributor / dbg bit 1)
             if (sk_finish) {
                 // stream-K finisher: block seq0+1 wrote its partial of this tile as the first thing it did
                 if (tid == 0) {
@@ -766,9 +800,176 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                 __builtin_amdgcn_s_barrier();
                 EW3_FENCE();
                 if (tid == 0) __hip_atomic_store(sk.flags + seq0, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
+            } else if constexpr (!RES_LDS) {
                 if (full) epilogue(std::true_type{}); else epilogue(std::false_type{});
                 // the patch lives in the slot the next position's DMA will overwrite
+                EW3_WAIT_LGKM0();
+                EW3_FENCE();
+                __builtin_amdgcn_s_barrier();
+                EW3_FENCE();
+            } else {
+                res_run = true;
+            }
+            if constexpr (RES_LDS) {
+                // ---- DIRECT epilogue with the residual tiles landing in LDS (round 5) ----
+                // Operand tile of one row fragment i (16 rows x 160 columns of this wave): hi plane 5 KB = 5 LDS-DMA instructions
+                // (instruction q, lane L: row L & 15, the 16-byte chunk q * 4 + (L >> 4) -- exactly the lane's operand of epilogue
+                // step (i, q), so the read-back is one conflict-free ds_read_b128 at lane * 16), lo8 plane 2.5 KB = 3 instructions
+                // ([10 chunks of 16 columns][16 rows] x 16 B, the last one on lanes 0-31 only; read back as ds_read_b64).
+                // Landing zones: one per wave (STAGE / 8 = 9 KB) in each of the two stages (wave-private: no workgroup barrier between
+                // the DMA and the read-back, only the wave's own counted vmcnt).  One residual: fragments i alternate between the
+                // two stages, two fragments in flight (B0 B1 | S0 | B2 | S1 | B3 | S2 | KT | S3); two residuals: r1 in one stage, r2
+                // in the other, one fragment in flight.  vmcnt retires in order: a wait for batch Bi names the instructions issued
+                // AFTER it (the stores Sj of 10 instructions per fragment, later batches of 8 / 16, the 9 pieces KT of the next
+                // K-tile) -- exact on full tiles; on edge tiles (stores masked, possibly skipped) only the DMA instructions count.
+                constexpr bool R1 = EPI & 2, R2 = EPI & 4, LO = EPI & 16;
+                constexpr int NQ = FN / 2;
+                constexpr int NOPD = (R1 && R2) ? 2 : 1;                 // residual operands
+                constexpr int HI_B = NQ * 1024;                           // hi plane of one fragment tile (5 KB at BN = 320, 4 KB at 256)
+                constexpr int LO_CH = WN / 16, LO_I = (LO_CH + 3) / 4;    // lo8 plane: 16-column chunks per row, LDS-DMA instructions (the last one partial at BN = 320)
+                constexpr int ZONE = STAGE / NW;                          // landing zone of one wave in one stage
+                static_assert(HI_B + LO_I * 1024 <= ZONE, "landing zone");
+                constexpr int BI = NOPD * (NQ + (LO ? LO_I : 0));         // DMA instructions per batch
+                constexpr int SI = NQ * (LO ? 2 : 1);                     // store instructions per row fragment
+                char* const stage_next = smem + s_cur * STAGE;            // stage of stream position v+1 (free since the barrier of position v-1)
+                char* const stage_done = smem + (s_cur ^ 1) * STAGE;      // stage just consumed (free since this position's barrier)
+                const bool deferred = pend;                               // K-tile v+1 exists and has not been staged yet
+                const bool exact = full && !(p.dbg & 1) && (!LO || p.out_lo);       // every store instruction of a fragment is issued
+#define EW3_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+                auto res_phase = [&](auto phase_tag) __attribute__((always_inline)) {
+                    constexpr int PH = decltype(phase_tag)::value;        // 0: fragments 0 .. FM-2 (one residual) or all (two), 1: fragment FM-1 (one residual)
+                    int lane_e = tid & 63;                                // opaque copy: keeps the per-lane constants out of the main loop
+                    asm volatile("" : "+v"(lane_e));
+                    const int frow = lane_e & 15, fks = lane_e >> 4;
+                    const unsigned hi_rd = lane_e * 16;
+                    const unsigned lo_rd = HI_B + (((fks >> 1) * 16 + frow) * 16) + (fks & 1) * 8;
+                    const char* r1p = (const char*)(p.r1 ? p.r1 : p.zero_page);
+                    const char* r2p = (const char*)(p.r2 ? p.r2 : p.zero_page);
+                    const char* r1lp = (const char*)(p.r1_lo ? (const void*)p.r1_lo : (const void*)p.zero_page);
+                    const char* r2lp = (const char*)(p.r2_lo ? (const void*)p.r2_lo : (const void*)p.zero_page);
+                    const int m1 = p.r1 ? 1 : 0, m2 = p.r2 ? 1 : 0, m1l = p.r1_lo ? 1 : 0, m2l = p.r2_lo ? 1 : 0;
+                    const int ld1 = p.r1 ? p.ld_r1 : 0, ld2 = p.r2 ? p.ld_r2 : 0, ld1l = p.r1_lo ? p.ld_r1 : 0, ld2l = p.r2_lo ? p.ld_r2 : 0;
+                    char* const za = stage_next + wave * ZONE;            // landing zones of this wave
+                    char* const zb = stage_done + wave * ZONE;
+                    // one operand's tile of row fragment i -> zone
+                    auto issue1 = [&](const char* rp, const char* rlp, int ld, int mm, int ldl, int mml, int i, char* zone) __attribute__((always_inline)) {
+                        const int mc = min(m_w0 + i * 16 + frow, p.M - 1);
+                        const char* src = rp + (unsigned)(mc * ld + (n_w0 + fks * 8) * mm) * 2u;
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) glds16((const f16*)(src + q * 64 * mm), zone + q * 1024);
+                        if constexpr (LO) {
+                            const char* srcl = rlp + (unsigned)(mc * ldl + (n_w0 + fks * 16) * mml);
+#pragma unroll
+                            for (int tt = 0; tt < LO_I; ++tt) {
+                                if (tt * 4 + 4 <= LO_CH) glds16((const f16*)(srcl + tt * 64 * mml), zone + HI_B + tt * 1024);
+                                else if (lane_e < (LO_CH - tt * 4) * 16) glds16((const f16*)(srcl + tt * 64 * mml), zone + HI_B + tt * 1024);
+                            }
+                        }
+                    };
+                    auto issue = [&](int i) __attribute__((always_inline)) {
+                        if constexpr (NOPD == 2) {
+                            issue1(r1p, r1lp, ld1, m1, ld1l, m1l, i, za);
+                            issue1(r2p, r2lp, ld2, m2, ld2l, m2l, i, zb);
+                        } else if constexpr (R1) {
+                            issue1(r1p, r1lp, ld1, m1, ld1l, m1l, i, (i & 1) ? zb : za);
+                        } else {
+                            issue1(r2p, r2lp, ld2, m2, ld2l, m2l, i, (i & 1) ? zb : za);
+                        }
+                    };
+                    auto process = [&](int i) __attribute__((always_inline)) {
+                        const char* z1 = NOPD == 2 ? za : ((i & 1) ? zb : za);     // first (or only) operand
+                        const char* z2 = zb;                                        // second operand (NOPD == 2)
+                        f16x8 h1[NQ], h2[NQ];
+                        u32x2 l1[NQ], l2[NQ];
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            h1[q] = *(const f16x8*)(z1 + hi_rd + q * 1024);
+                            if constexpr (LO) l1[q] = *(const u32x2*)(z1 + lo_rd + q * 512);
+                            if constexpr (NOPD == 2) {
+                                h2[q] = *(const f16x8*)(z2 + hi_rd + q * 1024);
+                                if constexpr (LO) l2[q] = *(const u32x2*)(z2 + lo_rd + q * 512);
+                            }
+                        }
+                        const int m = m_w0 + i * 16 + frow;
+                        const bool live = (m < p.M) && !(p.dbg & 1);
+                        const unsigned ob = (unsigned)(m * p.ld_out + n_w0 + fks * 8);
+                        const float ca = p.c_acc, cA = (NOPD == 2 || R1) ? p.c_r1 : p.c_r2, cB = p.c_r2;
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            const f32x4 a0 = acc[i][2 * q], a1 = acc[i][2 * q + 1];
+                            const float vv[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                            f16x8 o;
+                            u32x2 ol;
+                            int s8[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                float x = vv[e] * ca;
+                                if constexpr (LO) x += cA * ew_split_dec(h1[q][e], ew_sbyte(l1[q][e >> 2], e & 3));
+                                else x += cA * (float)h1[q][e];
+                                if constexpr (NOPD == 2) {
+                                    if constexpr (LO) x += cB * ew_split_dec(h2[q][e], ew_sbyte(l2[q][e >> 2], e & 3));
+                                    else x += cB * (float)h2[q][e];
+                                }
+                                o[e] = (f16)x;
+                                if constexpr (LO) s8[e] = ew_split_enc(x, o[e]);
+                            }
+                            if constexpr (LO) { ol[0] = ew_pack4(s8[0], s8[1], s8[2], s8[3]); ol[1] = ew_pack4(s8[4], s8[5], s8[6], s8[7]); }
+                            if (live) {
+                                *(f16x8*)((char*)p.out + (ob + q * 32) * 2u) = o;
+                                if constexpr (LO) {
+                                    if (p.out_lo) *(u32x2*)((char*)p.out_lo + (ob + q * 32)) = ol;
+                                }
+                            }
+                        }
+                    };
+                    if constexpr (PH == 0) {
+                        if constexpr (NOPD == 1) {
+                            issue(0);
+                            issue(1);
+#pragma unroll
+                            for (int i = 0; i < FM - 1; ++i) {
+                                // batch i landed?  issued after it so far: B(i+1), and the stores of fragment i-1 (between B(i) .. no: see order)
+                                // order: B0 B1 | S0 B2 | S1 B3 | S2 ...  -> newer than B(i): i == 0: B1;  i >= 1: S(i-1), B(i+1)
+                                if (i == 0 || !exact) EW3_VMCNT(BI); else EW3_VMCNT(BI + SI);
+                                process(i);
+                                EW3_FENCE();
+                                if (i + 2 < FM) issue(i + 2);
+                            }
+                        } else {
+                            // two residuals: both stages hold operands of EVERY fragment, so all FM fragments are done here and K-tile
+                            // v+1 is staged after the last one
+                            issue(0);
+#pragma unroll
+                            for (int i = 0; i < FM; ++i) {
+                                EW3_VMCNT(0);
+                                process(i);
+                                EW3_FENCE();
+                                if (i + 1 < FM) issue(i + 1);
+                            }
+                        }
+                    } else if constexpr (NOPD == 1) {
+                        // fragment FM-1 (its zone is in stage_done): newer than its batch are the stores of fragment FM-2 and, when staged,
+                        // the 9 pieces of K-tile v+1
+                        if (exact) { if (deferred) EW3_VMCNT(SI + NP); else EW3_VMCNT(SI); }
+                        else { if (deferred) EW3_VMCNT(NP); else EW3_VMCNT(0); }
+                        process(FM - 1);
+                    }
+                };
+                if (res_run) res_phase(std::integral_constant<int, 0>{});
+                if (deferred) {
+                    // every wave has read what it needs from stage_next (fragments 0 .. FM-2 done): stage K-tile v+1 there
+                    EW3_WAIT_LGKM0();
+                    EW3_FENCE();
+                    __builtin_amdgcn_s_barrier();
+                    EW3_FENCE();
+                    stage_begin(stage_next);
+                    ++staged;
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) stage_piece(k);
+                }
+                if (res_run) res_phase(std::integral_constant<int, 1>{});
+                // K-tile v+1 landed (newer: the stores of the last fragment), every wave done with its landing zones
+                if (NOPD == 1 && res_run && exact) EW3_VMCNT(SI); else EW3_WAIT_VM0();
                 EW3_WAIT_LGKM0();
                 EW3_FENCE();
                 __builtin_amdgcn_s_barrier();
@@ -940,6 +1141,8 @@ ew_status dispatch_epi3(const GemmP& p, hipStream_t s) {
     }
     const int mask = (p.rowbias ? 1 : 0) | (p.r1 ? 2 : 0) | (p.r2 ? 4 : 0);
     if (p.r1_lo || p.r2_lo || p.out_lo) {           // split-fp16 residual stream: general path with the lo companions
+        // no residual operand (round 5): the row-bias enters through the accumulators' initial value, the epilogue only converts and stores
+        if (EW_G3_RB_INIT && (mask & 6) == 0) return launch3<MODE, 16 | 1>(p, s);
         if constexpr (MODE == EW_A_DENSE) {
             if ((mask & 4) == 0) return launch3<MODE, 16 | 3>(p, s);
             return launch3<MODE, 16 | 7>(p, s);
