@@ -347,6 +347,8 @@ def main():
         for q in range(0, world, 2):
             if not torch.equal(res[q], res[q + 1]):
                 raise SystemExit(f"CFG pair {q // 2}: the two members returned different latents")
+            if q and torch.equal(res[q], res[0]):      # pairs carry different clips (seed 10 + pair)
+                raise SystemExit(f"CFG pair {q // 2} returned the latents of pair 0: pairs must work on different clips")
     from evoworld_amd import ops as _ops
     _ops.streamk_check()                      # (pipe.denoise already checked after every clip; this covers the hooked forward too)
 

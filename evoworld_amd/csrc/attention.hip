@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
 #if EW_ATTN_SCALAR_FMA
                     const float t[2] = {PRE ? sacc[blk][r] : fmaf(sacc[blk][r], sl2, nm2[0]), PRE ? sacc[blk][r + 1] : fmaf(sacc[blk][r + 1], sl2, nm2[0])};
 #else
+                    static_assert(!PRE, "EW_ATTN_SCALAR_FMA=0 (packed-fma ablation) is only valid without the log2 pre-scaling: with PRE the MFMA C operand has already subtracted the running max");
                     const f32x2 sv = {sacc[blk][r], sacc[blk][r + 1]};
                     const f32x2 t = __builtin_elementwise_fma(sv, sl22, nm2);          // v_pk_fma_f32: two scores per VALU issue
 #endif

@@ -740,6 +740,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                     while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
                         __builtin_amdgcn_s_sleep(8);
                         if (++spins > (1 << 24)) {             // ~10 s: never hang the device; poison the flag word so the host sees it
+                            // (which launch: its epoch goes next to the poison word; the host keeps a ring of launch descriptions per workspace)
+                            __hip_atomic_store(sk.flags + 1025, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             __hip_atomic_store(sk.flags + 1024, 0xdeadu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             break;
                         }
@@ -991,7 +993,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
 }
 
 // ---- stream-K workspace: one per (device, stream) -- launches on one stream are ordered, so consecutive GEMMs may share it ----
-struct SkWorkspace { int dev; hipStream_t stream; float* ws; unsigned* flags; unsigned epoch; };
+struct SkDesc { unsigned epoch; int mode, epi, M, N, K; };                   // what a stream-K launch was (named when its hand-over times out)
+constexpr int SK_DESC_RING = 1024;
+struct SkWorkspace { int dev; hipStream_t stream; float* ws; unsigned* flags; unsigned epoch; SkDesc* ring; };
 constexpr int SK_SLOTS = 256;
 constexpr size_t SK_SLOT_FLOATS = (size_t)FM * FN * 4 * 64 * NW;          // 160 accumulators x 512 threads = 320 KB
 constexpr int SK_POOL = 64;                                                  // (device, stream) pairs of the whole process
@@ -1010,18 +1014,21 @@ SkWorkspace* sk_workspace(hipStream_t stream, bool create) {
     for (int i = 0; i < used; ++i)
         if (pool[i].dev == dev && pool[i].stream == stream) return &pool[i];
     if (!create || used == SK_POOL) return nullptr;                         // pool full: those launches run the whole-tile schedule
-    SkWorkspace w{dev, stream, nullptr, nullptr, 0};
+    SkWorkspace w{dev, stream, nullptr, nullptr, 0, nullptr};
     // uncached (MTYPE UC) device memory: partials and flags cross XCDs inside one kernel, and the per-XCD L2s are only coherent
     // at kernel boundaries for ordinary allocations
     if (hipExtMallocWithFlags((void**)&w.ws, SK_SLOTS * SK_SLOT_FLOATS * sizeof(float), hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     if (hipExtMallocWithFlags((void**)&w.flags, 2048 * sizeof(unsigned), hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(w.ws); return nullptr; }
     if (hipMemsetAsync(w.flags, 0, 2048 * sizeof(unsigned), stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(w.flags); (void)hipFree(w.ws); return nullptr; }
+    w.ring = new SkDesc[SK_DESC_RING]();
     pool[used] = w;
     return &pool[used++];
 }
-unsigned sk_next_epoch(SkWorkspace* w) {
+unsigned sk_next_epoch(SkWorkspace* w, int mode, int epi, const GemmP& p) {
     std::lock_guard<std::mutex> lock(sk_mutex);
-    return ++w->epoch;
+    const unsigned e = ++w->epoch;
+    w->ring[e % SK_DESC_RING] = SkDesc{e, mode, epi, p.M, p.N, p.K};
+    return e;
 }
 
 }  // namespace
@@ -1050,9 +1057,20 @@ int ew_gemm3_sk_status_b256() {
     for (int i = 0; i < SK_POOL; ++i) {
         SkWorkspace* w = sk_pool_entry(i);
         if (!w) break;
-        unsigned word = 0;
-        if (hipMemcpy(&word, w->flags + 1024, sizeof(word), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
-        if (word) bad = 1;
+        unsigned word[2] = {0, 0};
+        if (hipMemcpy(word, w->flags + 1024, sizeof(word), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        if (word[0]) {
+            bad = 1;
+            const SkDesc d = w->ring[word[1] % SK_DESC_RING];
+            char msg[256];
+            if (d.epoch == word[1])
+                snprintf(msg, sizeof(msg), "stream-K hand-over timed out: " EW3_KERNEL_STR "<%d, %d> M=%d N=%d K=%d (stream-K launch #%u on device %d, stream %p): the output of that launch is invalid",
+                         d.mode, d.epi, d.M, d.N, d.K, word[1], w->dev, (void*)w->stream);
+            else
+                snprintf(msg, sizeof(msg), "stream-K hand-over timed out in stream-K launch #%u on device %d, stream %p (more than %d stream-K launches ago: description no longer kept)",
+                         word[1], w->dev, (void*)w->stream, SK_DESC_RING);
+            ew_set_error("%s", msg);
+        }
     }
     return bad;
 }
@@ -1108,7 +1126,7 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
             if (w) {
                 sk.dp_rounds = (int)(tiles / 256) - 1;
                 sk.tiles = (int)(tiles - 256LL * sk.dp_rounds);
-                sk.ws = w->ws; sk.flags = w->flags; sk.epoch = sk_next_epoch(w);
+                sk.ws = w->ws; sk.flags = w->flags; sk.epoch = sk_next_epoch(w, MODE, EPI, p);
             }
         }
     }
@@ -1124,7 +1142,7 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
             grid = (int)(2 * tiles);
             sk.dp_rounds = 0;
             sk.tiles = (int)tiles;
-            sk.ws = w->ws; sk.flags = w->flags; sk.epoch = sk_next_epoch(w);
+            sk.ws = w->ws; sk.flags = w->flags; sk.epoch = sk_next_epoch(w, MODE, EPI, p);
         }
     }
     snprintf(g_gemm_last_kernel, 64, EW3_KERNEL_STR "<%d, %d>", MODE, EPI);
@@ -1168,7 +1186,7 @@ ew_status dispatch_epi3(const GemmP& p, hipStream_t s) {
 }  // namespace
 
 // true when generation 3 can run the problem AND is expected to be the faster choice (enough 256x320 tiles to fill the chip)
-bool EW3_NAME(ew_gemm3_wants)(const GemmP& p) {
+bool EW3_NAME(ew_gemm3_wants)(const GemmP& p, hipStream_t s) {
     // smallest M: the swapped-operand V^T projections (M = C = 320 / 640 / 1280 rows of W_v against N = all tokens) measured
     // 337 -> 253 us (level 0) and 192 -> 156 us (level 1) here against generation 2's 256x160 tiles (640-byte instead of 320-byte output
     // row pieces; profiles/r04_f_sweeps.txt); EW_G3_MINM is the A/B hook (round 3 value: 1024)
@@ -1192,7 +1210,13 @@ bool EW3_NAME(ew_gemm3_wants)(const GemmP& p) {
     if (tiles >= 200) return true;
     // fewer tiles than CUs: generation 3 only with the half split (launch3), i.e. not for the one variant compiled without it
     const bool epi23 = p.mode == EW_A_DENSE && p.r2 && (p.r1_lo || p.r2_lo || p.out_lo);        // dispatch_epi3: <0, 16|7>
-    return !epi23 && p.act != EW_ACT_GEGLU && sk_half_shape(p, tiles);
+    if (epi23 || p.act == EW_ACT_GEGLU || !sk_half_shape(p, tiles)) return false;
+    // ... and only when launch3 can really set the split up: a (device, stream) workspace exists or may be created now (not while the
+    // stream is being captured without a prior ew_gemm_streamk_init, not with the pool full / out of memory) -- otherwise the problem would
+    // run whole tiles on fewer than half of the CUs, and generation 2 is the faster choice
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    return sk_workspace(s, cap == hipStreamCaptureStatusNone) != nullptr;
 }
 
 ew_status EW3_NAME(ew_gemm3_dispatch)(const GemmP& p, hipStream_t s) {

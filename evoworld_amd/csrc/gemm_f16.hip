@@ -280,9 +280,9 @@ ew_status launch(const GemmP& p, hipStream_t s) {
 
 ew_status ew_gemm2_dispatch(const GemmP& p, hipStream_t s);   // gemm2_f16.hip
 ew_status ew_gemm3_dispatch(const GemmP& p, hipStream_t s);   // gemm3_f16.hip
-bool ew_gemm3_wants(const GemmP& p);
+bool ew_gemm3_wants(const GemmP& p, hipStream_t s);
 ew_status ew_gemm3_dispatch_b256(const GemmP& p, hipStream_t s);   // gemm3_f16.hip compiled with EW3_BN=256
-bool ew_gemm3_wants_b256(const GemmP& p);
+bool ew_gemm3_wants_b256(const GemmP& p, hipStream_t s);
 static int g_gemm_gen = -1;
 char g_gemm_last_kernel[64] = "";          // rocprof-style name of the kernel the last ew_gemm_f16 call launched
 extern "C" const char* ew_gemm_last_kernel(void) { return g_gemm_last_kernel; }
@@ -346,8 +346,8 @@ extern "C" ew_status ew_gemm_f16(const ew_gemm_args* a, void* stream) {
     p.dbg = g_gemm_dbg;
     hipStream_t s = (hipStream_t)stream;
     // generation 3 (256x320 tile) where it applies and fills the chip, generation 2 otherwise
-    if (ew_get_gemm_generation() >= 3 && ew_gemm3_wants(p)) return ew_gemm3_dispatch(p, s);
-    if (ew_get_gemm_generation() >= 3 && ew_gemm3_wants_b256(p)) return ew_gemm3_dispatch_b256(p, s);
+    if (ew_get_gemm_generation() >= 3 && ew_gemm3_wants(p, s)) return ew_gemm3_dispatch(p, s);
+    if (ew_get_gemm_generation() >= 3 && ew_gemm3_wants_b256(p, s)) return ew_gemm3_dispatch_b256(p, s);
     if (ew_get_gemm_generation() >= 2) return ew_gemm2_dispatch(p, s);
     // generation 1 tile choice: every channel count of the U-Net is a multiple of 160 (320*k); GEGLU and odd sizes use 128
     if (a->act != EW_ACT_GEGLU && a->N % 160 == 0) { snprintf(g_gemm_last_kernel, 64, "gemm_kernel<128, 160>"); return launch<128, 160>(p, s); }

@@ -7,7 +7,8 @@
   (pipeline_evoworld.py:691-711) are independent until the combine at :709-711.  Ranks 2p and 2p+1 form pair p; each runs the
   U-Net on ONE row (B = 1), the two eps rows ([T*h*w, 4] fp16 = 1.84 MB at 72x128x25) meet in ONE all_gather per step over
   xGMI, and the CFG combine + Euler step is replicated (every rank keeps the full latents and both rows of the next model
-  input, so nothing else is exchanged).  This is the axis that moves frames/s PER CLIP: ~1.9x at 2 GPUs (strong scaling)."""
+  input, so nothing else is exchanged).  This is the axis that moves frames/s PER CLIP: projected about 1.84x at 2 GPUs from one-GPU
+  B = 1 forward timings (strong scaling; UNMEASURED on multi-GPU hardware)."""
 import os
 
 import torch
@@ -86,12 +87,14 @@ class CfgGroup:
         if size not in (1, 2) or world % size:
             raise ValueError(f"CFG group size must be 1 or 2 and divide the world size (size={size}, world={world})")
         self.size, self.member, self.pair, self.n_pairs = size, rank % size, rank // size, world // size
-        self.group = None
+        self.group, self._flat = None, False
         if dist.is_available() and dist.is_initialized():
             for p in range(self.n_pairs):               # new_group is collective: every rank creates every pair's group
                 g = dist.new_group(ranks=list(range(p * size, (p + 1) * size)))
                 if p == self.pair:
                     self.group = g
+            # RCCL ("nccl") has the flat all_gather_into_tensor; gloo takes the list form
+            self._flat = self.group is not None and dist.get_backend(self.group) == "nccl"
 
     def rows(self):
         """CFG rows this rank runs the U-Net for"""
@@ -108,9 +111,9 @@ class CfgGroup:
             return eps_all
         if self.group is None:
             raise RuntimeError("CfgGroup(size=2) needs an initialised process group")
-        try:
+        # the form is chosen ONCE from the backend (no try / except: a failing collective must propagate, not be retried as another one)
+        if self._flat:
             dist.all_gather_into_tensor(eps_all.view(-1), mine.contiguous().view(-1), group=self.group)
-        except (RuntimeError, NotImplementedError):      # backends without the flat form (older gloo)
-            out = [eps_all[0], eps_all[1]]
-            dist.all_gather(out, mine.contiguous(), group=self.group)
+        else:
+            dist.all_gather([eps_all[0], eps_all[1]], mine.contiguous(), group=self.group)
         return eps_all

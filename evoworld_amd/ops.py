@@ -144,7 +144,8 @@ def streamk_check():
     call it where results are handed to the caller (end of a denoise loop / U-Net call / bench), not per launch."""
     st = _lib.load().ew_gemm_streamk_status()
     if st != 0:
-        raise _lib.EvoWorldHipError("stream-K hand-over timed out in ew_gemm_f16 (generation 3): results of that launch are invalid"
+        msg = _lib.load().ew_last_error()          # names the launch (kernel variant, M / N / K, stream) when the time-out was recorded
+        raise _lib.EvoWorldHipError((msg.decode() if msg else "stream-K hand-over timed out in ew_gemm_f16 (generation 3): results of that launch are invalid")
                                     if st > 0 else "ew_gemm_streamk_status: HIP error while reading the status word")
 
 

@@ -423,7 +423,7 @@ class UNetSpatioTemporalConditionModel:
                     # level 0: the LayerNorm + GEGLU feed-forward pairs run as ONE kernel (ew_ff_geglu320_f16) on LDS-image packs
                     for nm, ff in ((f"{tag}_ffp", ".ff"),) + (((f"{tag}_fip", ".ff_in"),) if tag == "t" else ()):
                         d[nm] = ops.ff_pack(f32(b + ff + ".net.0.proj.weight"), f32(b + ff + ".net.0.proj.bias"), f32(b + ff + ".net.2.weight"))
-                    if True:                    # norm3 folded into the up-projection of .ff (round 4, EW_FUSED_FF=3): W1 diag(gamma), b1 + W1 beta
+                    if self.fused_ff == 3:      # norm3 folded into the up-projection of .ff (round 4, EW_FUSED_FF=3): W1 diag(gamma), b1 + W1 beta
                         d[f"{tag}_ffp_ln"] = ops.ff_pack(f32(b + ".ff.net.0.proj.weight"), f32(b + ".ff.net.0.proj.bias"), f32(b + ".ff.net.2.weight"),
                                                          ln=(f32(b + ".norm3.weight"), f32(b + ".norm3.bias")))
             W[t.p] = d

@@ -117,3 +117,52 @@ def test_cfg_group_degenerate_and_validation():
         D.CfgGroup(0, 3, size=2)
     with pytest.raises(ValueError):
         D.CfgGroup(0, 4, size=4)
+
+
+def _cfg4_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from evoworld_amd import distributed as D
+    r, w, _ = D.init(backend="gloo")
+    grp = D.CfgGroup(r, w, size=2)
+    members = dist.get_process_group_ranks(grp.group)
+    rows = 24
+    outs = []
+    for step in range(2):
+        # "this rank's forward output": depends on the CLIP (= pair) and on the CFG row, not on the rank id directly
+        eps_all = torch.zeros(2, rows, 4, dtype=torch.float16)
+        (row,) = grp.rows()
+        mine = torch.full((rows, 4), float(100 * grp.pair + 10 * row + step), dtype=torch.float16)
+        eps_all[row].copy_(mine)
+        grp.all_gather_rows(eps_all, mine)
+        outs.append(eps_all.clone())
+    # one clip per pair: the clip sharding of the cfg2 x dp(N/2) layout
+    clips = D.shard_clips(4, grp.pair, grp.n_pairs)
+    D.barrier()
+    q.put((r, grp.pair, grp.member, grp.n_pairs, members, grp.rows(), clips, torch.stack(outs).numpy()))
+
+
+def test_cfg_two_pairs_world4_gloo():
+    """cfg2 x dp2 (what `bench.py --gpus 4 --split cfg` builds, and cfg2 x dp4 at 8 GPUs): ranks (0,1) and (2,3) form two pairs, `new_group`
+    is called for every pair on every rank in the same order, the members of a pair end up bit-identical, different pairs carry different
+    clips and never see each other's rows."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_cfg4_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in ps), key=lambda t: t[0])
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r, pair, member, n_pairs, members, rows, clips, outs in res:
+        assert pair == r // 2 and member == r % 2 and n_pairs == 2
+        assert members == [2 * pair, 2 * pair + 1]                 # the group this rank kept is its own pair's
+        assert rows == [member]                                    # rank 2p: unconditional row, 2p+1: conditional row
+        assert clips == [pair, pair + 2]                           # clips are sharded over PAIRS
+        for step in range(2):
+            want = torch.stack([torch.full((24, 4), float(100 * pair + 10 * row + step)) for row in range(2)]).half()
+            assert torch.equal(torch.from_numpy(outs[step]), want)
+    assert (res[0][7] == res[1][7]).all() and (res[2][7] == res[3][7]).all()      # pair members bit-identical
+    assert (res[0][7] != res[2][7]).any()                                          # different pairs, different clips

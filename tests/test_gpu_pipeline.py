@@ -12,11 +12,12 @@ pytestmark = pytest.mark.gpu
 # model prediction amplified by the CFG combination, and for these inputs the fp16-operand floor alone -- operands of every
 # conv / linear and of the attention matmuls rounded to fp16, everything else fp32 -- is 1.04e-3 ... 1.06e-3
 # (tests/analysis_fp16_floor.py --per-timestep): no design on fp16 MFMA operands can meet 1e-3 there.  The build measures
-# 1.25e-3 / 1.36e-3 (mask_mem) = 1.2 ... 1.3 x that floor; asserted at 1.6e-3 (1.5 x the floor).  The 2-step clip through the
-# stand-in VAE (smooth latents, the worst case measured) is 2.3e-3, asserted at 3.4e-3.
-TOL_CLIP3 = 1.6e-3
+# 1.10e-3 / 1.28e-3 (mask_mem; driver run of round 4) = 1.05 ... 1.2 x that floor.  Round 5: asserted at 1.15 x the MEASURED value instead of
+# 1.5 x the floor (1.5e-3), so that a 20 % regression fails.  The 2-step clip through the stand-in VAE (smooth latents, the worst case
+# measured) is 2.1e-3, asserted at 2.5e-3.
+TOL_CLIP3 = 1.5e-3
 TOL_CLIP25 = 6.2e-4
-TOL_CLIP2_STANDIN = 3.4e-3
+TOL_CLIP2_STANDIN = 2.5e-3
 
 
 class _FakeVAE:
@@ -234,6 +235,22 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(split):
     assert line["n_gpus"] == 2 and line["value"] > 0
     assert line["config"]["parallelism"] == ("dp2" if split == "clip" else "cfg2 x dp1")
     assert line["scaling"] == ("weak" if split == "clip" else "strong")
+
+
+def test_bench_two_cfg_pairs_on_one_gpu_over_gloo():
+    """cfg2 x dp2 -- the layout `bench.py --gpus 4 --split cfg` (and, with four pairs, --gpus 8) uses -- with four real ranks sharing cuda:0
+    over gloo: one process group per pair created on every rank, pair members bit-identical (bench.py asserts it), two clips in the job."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "EW_FORCE_DIST")}
+    env.update(EW_SHARE_GPU="1", EW_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--tiny", "--steps", "1", "--warmup", "0", "--denoise-steps", "2",
+                        "--height", "128", "--width", "256", "--no-cpu-baseline", "--split", "cfg"], capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "weight broadcast to 4 rank(s)" in r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 4 and line["value"] > 0
+    assert line["config"]["parallelism"] == "cfg2 x dp2" and line["scaling"] == "weak"
 
 
 @pytest.mark.skipif(not __import__("os").environ.get("EW_FULL_PARITY_STEPS"),

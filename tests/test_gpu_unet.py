@@ -4,10 +4,10 @@ Stated tolerance (BASELINE.json north_star): 1e-3 rel-L2 on the model OUTPUT.  f
 against the fp32 oracle -- of which 7.5e-4 ... 8.0e-4 is the floor of ANY design that feeds fp16 operands to the MFMA
 (tests/analysis_fp16_floor.py: operands of every conv / linear AND of the attention matmuls rounded, nothing else).
 The OUTPUT assertion is the north_star's 1e-3.  The per-block TAPS are internal tensors, not outputs: the error peaks at the
-bottleneck (mid / up0: 1.17e-3 tiny, 1.01e-3 full size) and falls again towards the output; they are asserted at 1.5e-3
-(a 20 % regression of the worst tap fails)."""
+bottleneck (mid / up0: 1.17e-3 tiny, 1.01e-3 full size) and falls again towards the output; they are asserted at 1.4e-3
+(1.2 x the worst tap)."""
 TOL_FORWARD = 1.0e-3
-TOL_TAP = 1.5e-3
+TOL_TAP = 1.4e-3
 # SURVEY §8d weight protocol (oracle keeps fp32 weights, HIP packs them to fp16): rounding 1.5 G weights to fp16 is one more
 # operand-rounding term of the same size as the activations' -- the fp16-operand floor of ONE forward rises from 7.5e-4 to
 # 1.05e-3 (tests/analysis_fp16_floor.py main(): "(a) fp16 operands only"), so one forward of an fp32 checkpoint cannot meet
@@ -79,7 +79,7 @@ def test_unet_tiny_vs_oracle_fp32_weights():
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
-def test_unet_level0_320_fused_feed_forward_modes(mode):
+def test_unet_level0_320_fused_feed_forward_modes(mode, monkeypatch):
     """A shrunken config whose FIRST level has the real 320 channels (head_dim 64, hidden 1280), so that its three feed-forwards go through
     ew_ff_geglu320_f16: mode 0 = LayerNorm + two GEMMs, 1 = LayerNorm kernel + fused kernel (default), 2 = LayerNorm in the fused kernel's
     prologue, 3 = norm3 folded into the up-projection of .ff (hi plane normalised in registers).  Every mode is checked against the fp32 oracle at the
@@ -89,8 +89,9 @@ def test_unet_level0_320_fused_feed_forward_modes(mode):
     cfg["block_out_channels"] = (320, 128, 256, 256)
     cfg["num_attention_heads"] = (5, 2, 4, 4)
     B, T, h, w = 2, 4, 16, 32
+    monkeypatch.setenv("EW_FUSED_FF", str(mode))     # read at construction: the folded-LayerNorm packs of mode 3 are only built when it is selected
     m, ref, x, ehs, ids = _setup(cfg, B, T, h, w, seed=11)
-    m.fused_ff = mode
+    assert m.fused_ff == mode
     t = torch.tensor(0.9)
     want = ref(x, t, ehs, ids)
     got = m(x.cuda(), t, ehs.cuda(), ids.cuda(), return_dict=False)[0]
