@@ -31,6 +31,13 @@
 #ifndef EW_ATTN_ROWSUM
 #define EW_ATTN_ROWSUM 0     /* 0: v_dot2c of the fp16-rounded P (round-toward-zero pack); 1: f32 adds of the exponentials + round-to-nearest pack (A/B, round 4) */
 #endif
+#ifndef EW_ATTN_LAZYMAX
+#define EW_ATTN_LAZYMAX 1    /* round 5 (log2 form only): no per-tile max in the hot path -- a tile's row sum (which the normaliser needs anyway) tells whether
+                                any of its exponentials left the safe range; only then, and on a sequence's first tile, the max chain + rescale run */
+#endif
+#ifndef EW_ATTN_VW64
+#define EW_ATTN_VW64 1       /* round 5: V^T tile written as four ds_write_b64 straight from the loaded registers instead of eight v_mov + two ds_write_b128 */
+#endif
 namespace {
 
 __device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
@@ -110,10 +117,25 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
         *(f16x8*)(kl + k_w0) = kr0;
         *(f16x8*)(kl + k_w1) = kr1;
         // 16-key group -> slot A = keys {0..3, 8..11}, slot B = keys {4..7, 12..15}
+#if EW_ATTN_VW64
+        // the loop is VALU-bound: the repack into two 16-byte registers cost eight v_mov per tile; four 8-byte LDS writes cost none
+        // (inline asm: hipcc merges adjacent 8-byte LDS stores back into ds_write_b128 + the moves; the __syncthreads after every write_tile waits
+        // with lgkmcnt(0) whatever the compiler tracked)
+        typedef __attribute__((address_space(3))) char* lds_t;
+        const unsigned a0 = (unsigned)(unsigned long long)(lds_t)(smem + k_w0), a1 = (unsigned)(unsigned long long)(lds_t)(smem + k_w1);
+        constexpr int VOFF = decltype(buf_tag)::value * 16384 + 8192;       // buffer and V^T half as the instruction's immediate offset: one address pair for both buffers
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t w0 = __builtin_bit_cast(u32x4_t, vr0), w1 = __builtin_bit_cast(u32x4_t, vr1);
+        const u32x2_t v0l = {w0[0], w0[1]}, v0h = {w0[2], w0[3]}, v1l = {w1[0], w1[1]}, v1h = {w1[2], w1[3]};
+        asm volatile("ds_write_b64 %0, %1 offset:%6\n\tds_write_b64 %0, %2 offset:%7\n\tds_write_b64 %3, %4 offset:%6\n\tds_write_b64 %3, %5 offset:%7"
+                     :: "v"(a0), "v"(v0l), "v"(v1l), "v"(a1), "v"(v0h), "v"(v1h), "n"(VOFF), "n"(VOFF + 8) : "memory");
+#else
         const f16x8 sa = {vr0[0], vr0[1], vr0[2], vr0[3], vr1[0], vr1[1], vr1[2], vr1[3]};
         const f16x8 sb = {vr0[4], vr0[5], vr0[6], vr0[7], vr1[4], vr1[5], vr1[6], vr1[7]};
         *(f16x8*)(vl + k_w0) = sa;   // same (row, slot) geometry as the K tile: row = srow (d), slots 2*sc, 2*sc+1
         *(f16x8*)(vl + k_w1) = sb;
+#endif
     };
 
     f32x16 oacc[2];
@@ -144,8 +166,13 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
     // One 64-key tile; the LDS buffer it reads (BUF) and the one it refills (BUF ^ 1) are compile-time constants: the loop is
     // unrolled by two below, so buffer selection costs no VALU (it used to be eight xors on the fragment offsets plus address
     // arithmetic on the four tile stores per iteration).
-    auto tile_step = [&](const int j, auto buf_tag) __attribute__((always_inline)) {
+    constexpr bool LAZY = PRE && bool(EW_ATTN_LAZYMAX) && EW_ATTN_ROWSUM == 0;
+    constexpr float LAZY_SUM_THR = 1024.f;   // a lane's 32 exponentials of a tile may sum to 2^10 before the max is looked at (each <= 2^10: far inside fp16)
+    constexpr float LAZY_RAISE_THR = 4.0f;   // ... and then every query whose tile max exceeds the running max by 2^4 is raised (a lane over the sum limit holds
+                                             // an element >= 2^5, so its query always is)
+    auto tile_step = [&](const int j, auto buf_tag, auto first_tag) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;        // LAZY: the sequence's first tile (peeled: it always sets the running max)
         const int key0 = j * 64;
         const char* kb = kl + BUF * 16384;
         const char* vb = vl + BUF * 16384;
@@ -188,6 +215,30 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
                 }
         }
         // ---- online softmax (this lane: one query, 32 of the 64 keys; partner lane^32 has the rest) ----
+        // LAZY: the max chain + cross-half exchange + rescale as a function, run on the first tile and when a row sum says so
+        auto lazy_fix = [&]() __attribute__((always_inline)) {
+            float tmax = fmaxf(sacc[0][0], sacc[0][1]);
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) tmax = fmaxf(fmaxf(tmax, sacc[0][r]), sacc[0][r + 1]);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) tmax = fmaxf(fmaxf(tmax, sacc[1][r]), sacc[1][r + 1]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            // the scores are already s - m_run: tmax is the increment.  First tile: it sets the max whatever its sign (m_run starts at 0, not -inf:
+            // an infinite C operand would poison the MFMA) and nothing is accumulated yet.
+            const float delta = FIRST ? tmax : (tmax > LAZY_RAISE_THR ? tmax : 0.f);
+            if constexpr (!FIRST) {
+                const float alpha = exp2f(-delta);
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+            }
+            m_run += delta;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sacc[0][i] -= delta; sacc[1][i] -= delta; negm[i] -= delta; }       // (negm in place: -(m + d) == (-m) - d exactly)
+        };
+        if constexpr (LAZY) {
+            if constexpr (FIRST) lazy_fix();
+        } else {
         float tmax = fmaxf(sacc[0][0], sacc[0][1]);
 #pragma unroll
         for (int r = 2; r < 16; r += 2) tmax = fmaxf(fmaxf(tmax, sacc[0][r]), sacc[0][r + 1]);      // v_max3_f32 chain
@@ -228,9 +279,13 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
             for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
         }
         }
+        }
         // P = exp2(S*c - m) -> fp16 pairs (round-toward-zero pack: one instruction per pair; its bias cancels because the
         // normaliser l below is accumulated from the SAME rounded values, with v_dot2)
         f16x8 pf[4];
+        float lt = 0.f;                       // LAZY: this tile's row sum (32 of the 64 keys)
+        auto compute_p = [&]() __attribute__((always_inline)) {
+        if constexpr (LAZY) lt = 0.f;
         const f32x2 nm2 = {-m_run, -m_run}, sl22 = {sl2, sl2};
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
@@ -258,7 +313,8 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
 #else
                     const h2_t ph = __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]));
                     const h2_t one = {(__fp16)1.0f, (__fp16)1.0f};
-                    l_run = __builtin_amdgcn_fdot2(ph, one, l_run, false);
+                    if constexpr (LAZY) lt = __builtin_amdgcn_fdot2(ph, one, lt, false);
+                    else l_run = __builtin_amdgcn_fdot2(ph, one, l_run, false);
 #endif
                     w[e] = __builtin_bit_cast(unsigned, ph);
                 }
@@ -266,6 +322,15 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
                 const u32x4 wv = {w[0], w[1], w[2], w[3]};
                 pf[blk * 2 + g2] = __builtin_bit_cast(f16x8, wv);
             }
+        };
+        compute_p();
+        if constexpr (LAZY) {
+            if constexpr (!FIRST) {
+                // !(lt <= thr) also catches a NaN sum (inf - inf cannot occur here, but an overflowed exponential must never pass)
+                if (__any(!(lt <= LAZY_SUM_THR))) { lazy_fix(); compute_p(); }
+            }
+            l_run += lt;
+        }
         // ---- O^T += V^T P^T ----
 #if EW_ATTN_PRIO == 2
         __builtin_amdgcn_s_setprio(1);
@@ -285,12 +350,22 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
         if (j + 1 < nt) write_tile(std::integral_constant<int, BUF ^ 1>{});
         __syncthreads();
     };
-    int j = 0;
-    for (; j + 1 < nt; j += 2) {
-        tile_step(j, std::integral_constant<int, 0>{});
-        tile_step(j + 1, std::integral_constant<int, 1>{});
+    if constexpr (LAZY) {
+        tile_step(0, std::integral_constant<int, 0>{}, std::true_type{});
+        int j = 1;
+        for (; j + 1 < nt; j += 2) {
+            tile_step(j, std::integral_constant<int, 1>{}, std::false_type{});
+            tile_step(j + 1, std::integral_constant<int, 0>{}, std::false_type{});
+        }
+        if (j < nt) tile_step(j, std::integral_constant<int, 1>{}, std::false_type{});
+    } else {
+        int j = 0;
+        for (; j + 1 < nt; j += 2) {
+            tile_step(j, std::integral_constant<int, 0>{}, std::false_type{});
+            tile_step(j + 1, std::integral_constant<int, 1>{}, std::false_type{});
+        }
+        if (j < nt) tile_step(j, std::integral_constant<int, 0>{}, std::false_type{});
     }
-    if (j < nt) tile_step(j, std::integral_constant<int, 0>{});
     // ---- normalise + store: lane holds query q_idx, d = 32*db + 8*(r>>2) + 4*lh + (r&3) ----
 #if EW_ATTN_ROWSUM == 1
     l_run += l_run2;

@@ -293,6 +293,39 @@ def test_attn_spatial_log2(ops, n_seq, S, heads, shift):
     assert e < 2e-3
 
 
+@pytest.mark.parametrize("pattern", ["ramp", "jumps", "overflow", "flat_below", "flat_above", "late_spike", "ragged_spike"])
+def test_attn_spatial_log2_lazy_max(ops, pattern):
+    """Round 5: the log2 kernel looks at a tile's maximum only when the tile's ROW SUM leaves the safe range (and on the first tile).  Score
+    profiles that stress exactly that decision: key j carries an offset f(j) in log2 units (q channel 0 = 1, k channel 0 = f) on top of random
+    scores -- slow ramps (many small raises), jumps up and down, jumps large enough to overflow the exponentials before the check sees them,
+    plateaus just below / just above the row-sum limit (32 keys x 2^4.9 = 955 < 1024 < 32 x 2^5.1), a spike in the very last (ragged) tile."""
+    n_seq, heads = 2, 2
+    S = 1000 if pattern == "ragged_spike" else 1024
+    C = heads * 64
+    rows = n_seq * S
+    qk32 = rnd(rows, 2 * C, seed=5) * 0.6
+    v = rnd(rows, C, seed=6).half().to(DEV)
+    t = (torch.arange(S) // 64).float()
+    f = {"ramp": 0.37 * t, "jumps": 30.0 * ((t % 3) == 2).float() - 12.0 * ((t % 5) == 1).float(), "overflow": 200.0 * t,
+         "flat_below": 4.9 * (t > 0).float(), "flat_above": 5.1 * (t > 0).float(), "late_spike": 25.0 * (t == 15).float(),
+         "ragged_spike": 40.0 * (torch.arange(S) >= 990).float()}[pattern]
+    for h in range(heads):
+        qk32[:, h * 64] = 1.0
+        qk32[:, C + h * 64] = f.repeat(n_seq) * (1.0 if h == 0 else -0.5)       # the second head sees the mirrored (falling) profile
+    qk = qk32.half().to(DEV)                          # already in log2 units: what ew_attn_spatial_log2_f16 takes
+    vt = v.T.contiguous()
+    o = torch.empty(rows, C, dtype=torch.float16, device=DEV)
+    ops.attn_spatial_log2(qk, qk[:, C:], vt, o, n_seq, S, heads, 2 * C, rows, C)
+    q = qk[:, :C].double().reshape(n_seq, S, heads, 64).transpose(1, 2)
+    k = qk[:, C:].double().reshape(n_seq, S, heads, 64).transpose(1, 2)
+    vv = v.double().reshape(n_seq, S, heads, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(q, k, vv, scale=math.log(2.0)).transpose(1, 2).reshape(rows, C)
+    assert torch.isfinite(o).all()
+    e = rel_l2(o.double().cpu(), ref.cpu())
+    print(f"attn_spatial_log2 lazy max, {pattern}: rel-L2 {e:.2e}")
+    assert e < 2e-3
+
+
 @pytest.mark.parametrize("B,T,S,heads", [(2, 25, 37, 2), (1, 4, 512, 1), (2, 1, 9, 3), (1, 32, 5, 1), (2, 49, 21, 2), (1, 64, 7, 1),
                                          (1, 33, 130, 3)])
 def test_attn_temporal(ops, B, T, S, heads):

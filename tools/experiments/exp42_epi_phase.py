@@ -48,19 +48,24 @@ def convt(B, T, P, C):
     return lambda: ops.gemm(x, w, out, M=M, N=C, c1=C, lda=C, bias=b, mode=ops.A_CONVT3, tconv=(B, T, P), r1=r1, ld_r1=C)
 
 
-cases = [("dense 115200x640x640 rb", lambda: dense(115200, 640, 640, True)), ("dense 28800x1280x1280 rb", lambda: dense(28800, 1280, 1280, True)),
-         ("dense 115200x640x2560", lambda: dense(115200, 640, 2560)), ("dense 28800x1280x5120", lambda: dense(28800, 1280, 5120)),
-         ("convT 460800x320x960", lambda: convt(2, 25, 9216, 320)), ("conv3x3 L0 460800x320x2880 res", lambda: conv(50, 320, 72, 128)),
-         ("conv3x3 L1 115200x640x5760 res", lambda: conv(50, 640, 36, 64)), ("conv3x3 L0 460800x320x2880 rb", lambda: conv(50, 320, 72, 128, False))]
-for name, mk in cases:
-    fn = mk()
-    row = []
-    for dbg in (0, 1, 2, 0, 1, 2):
-        lib.ew_set_gemm_debug(dbg)
-        row.append(timeit(fn))
-    lib.ew_set_gemm_debug(0)
-    fn()
-    k = lib.ew_gemm_last_kernel().decode()
-    print(f"{name:36s} {k:22s} full {min(row[0], row[3]):7.1f}  no-stores {min(row[1], row[4]):7.1f}  no-epilogue {min(row[2], row[5]):7.1f} us", flush=True)
-    del fn
-    torch.cuda.empty_cache()
+def main():
+    cases = [("dense 115200x640x640 rb", lambda: dense(115200, 640, 640, True)), ("dense 28800x1280x1280 rb", lambda: dense(28800, 1280, 1280, True)),
+             ("dense 115200x640x2560", lambda: dense(115200, 640, 2560)), ("dense 28800x1280x5120", lambda: dense(28800, 1280, 5120)),
+             ("convT 460800x320x960", lambda: convt(2, 25, 9216, 320)), ("conv3x3 L0 460800x320x2880 res", lambda: conv(50, 320, 72, 128)),
+             ("conv3x3 L1 115200x640x5760 res", lambda: conv(50, 640, 36, 64)), ("conv3x3 L0 460800x320x2880 rb", lambda: conv(50, 320, 72, 128, False))]
+    for name, mk in cases:
+        fn = mk()
+        row = []
+        for dbg in (0, 1, 2, 0, 1, 2):
+            lib.ew_set_gemm_debug(dbg)
+            row.append(timeit(fn))
+        lib.ew_set_gemm_debug(0)
+        fn()
+        k = lib.ew_gemm_last_kernel().decode()
+        print(f"{name:36s} {k:22s} full {min(row[0], row[3]):7.1f}  no-stores {min(row[1], row[4]):7.1f}  no-epilogue {min(row[2], row[5]):7.1f} us", flush=True)
+        del fn
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
