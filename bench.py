@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 ALGO_TFLOP_PER_FORWARD = 154.31      # SURVEY.md §8d, config 2, dead cross-attention work removed
 PEAK_F16_DENSE_TFLOPS = 2500.0       # MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16 MFMA
+NOMINAL_CLOCK_GHZ = 2.4              # the clock the dense peak is quoted at (256 CUs x 4 SIMDs x 1024 flop/clk x 2.4 GHz = 2.5 PFLOP/s)
 
 
 def source_fingerprint():
@@ -54,6 +55,23 @@ def committed_traffic(residual_mode):
     rec = tr.get("recorded_at", {})
     tr["stale"] = not (rec.get("source_fingerprint") == source_fingerprint() and rec.get("residual_stream") == residual_mode)
     return tr
+
+
+def committed_clock():
+    """Effective graphics clock of the forward's long kernels (diagnostic): GRBM_GUI_ACTIVE / kernel duration from the committed
+    `rocprofv3 --pmc GRBM_GUI_ACTIVE` pass (profiles/rNN_clock.json, tools/pmc_clock.sh), time-weighted over the launches of >= 300 us (the
+    counter window is a few us longer than the kernel, so short launches read high).  The chip clocks to its power budget: MFMA- and VALU-dense
+    kernels sustain 1.8-2.2 GHz of the 2.4 GHz the 2.5 PFLOP/s peak is quoted at.  A recorded measurement, like `traffic`."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_clock.json")))
+    try:
+        c = json.load(open(files[-1]))
+        ks = [k for k in c["kernels"] if k["ms"] / k["launches"] >= 0.3]
+        ghz = sum(k["ghz"] * k["ms"] for k in ks) / sum(k["ms"] for k in ks)
+        return {"file": os.path.relpath(files[-1], ROOT), "ghz": ghz,
+                "per_kernel": {k["kernel"]: round(k["ghz"], 3) for k in sorted(ks, key=lambda k: -k["ms"])[:8]}}
+    except (OSError, ValueError, IndexError, KeyError, ZeroDivisionError):
+        return None
 
 
 def synth_inputs(T, h, w, seed, device):
@@ -361,6 +379,7 @@ def main():
         algo = ALGO_TFLOP_PER_FORWARD / (2 if args.split == "cfg" else 1)     # cfg split: a forward is ONE CFG row (B = 1)
         ach = algo / (fw_ms / 1e3) if full else None
         tr = committed_traffic("split" if unet.split_residual else "fp16")
+        clk = committed_clock()
         line = {
             "metric": "panoramic frames/sec per clip (576x1024x25f, 25 denoise steps)",
             "value": n_clips * T * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -379,6 +398,10 @@ def main():
                          "frac": (ach / PEAK_F16_DENSE_TFLOPS) if ach else None,
                          "traffic": (tr or {}).get("bytes_per_forward") if full and tr and not tr["stale"] else None, "traffic_detail": tr,
                          "algorithmic_tflop_per_launch": algo,
+                         # diagnostic, not the headline: the peak scaled to the clock the long kernels actually sustain under the power limit
+                         "effective_clock_ghz": clk["ghz"] if clk else None, "nominal_clock_ghz": NOMINAL_CLOCK_GHZ,
+                         "frac_at_effective_clock": (ach / (PEAK_F16_DENSE_TFLOPS * clk["ghz"] / NOMINAL_CLOCK_GHZ)) if (ach and clk) else None,
+                         "clock_detail": clk,
                          "kernels": kernels},
         }
         if world == 1 and not args.no_cpu_baseline:

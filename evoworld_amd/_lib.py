@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EW_LIB_PATH") or os.path.join(_HERE, "libevoworld_hip.so")   # EW_LIB_PATH: ablation builds (tools/)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # every symbol declared in include/evoworld_hip.h
 SYMBOLS = [
@@ -23,7 +23,9 @@ SYMBOLS = [
     "ew_filter_compact", "ew_splat_cubemap", "ew_splat_resolve", "ew_equi2pers", "ew_resize_aa_u8",
     "ew_u8_hwc_to_f32_chw", "ew_f32_chw_to_u8_hwc", "ew_blur_axis_f32", "ew_bicubic_resize_f32", "ew_vit_patchify_f16",
     "ew_attn_small_f16", "ew_quant_rows_fp8", "ew_gemm_fp8",
+    "ew_set_cu_budget", "ew_get_cu_budget", "ew_stream_create_cu_mask", "ew_stream_destroy",
 ]
+_ABI8 = {"ew_set_cu_budget", "ew_get_cu_budget", "ew_stream_create_cu_mask", "ew_stream_destroy"}
 
 
 class GemmArgs(ctypes.Structure):
@@ -69,13 +71,14 @@ def load():
             f"{LIB_PATH} not found: build it with `make -C evoworld_amd/csrc` (hipcc --offload-arch=gfx950). "
             "evoworld_amd has no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
+    ablation = bool(os.environ.get("EW_LIB_PATH"))          # A/B against an older build of the library (tools/ab_lib.sh): ABI 7 is accepted there
     for s in SYMBOLS:
-        if not hasattr(lib, s):
+        if not hasattr(lib, s) and not (ablation and s in _ABI8):
             raise EvoWorldHipError(f"{LIB_PATH} does not export {s}")
     lib.ew_last_error.restype = c_char_p
     lib.ew_gemm_last_kernel.restype = c_char_p
     lib.ew_abi_version.restype = c_int
-    if lib.ew_abi_version() != ABI_VERSION:
+    if lib.ew_abi_version() != ABI_VERSION and not (ablation and lib.ew_abi_version() == 7):
         raise EvoWorldHipError(f"ABI mismatch: library {lib.ew_abi_version()} != binding {ABI_VERSION}")
     P, I, F, LL = c_void_p, c_int, c_float, c_longlong
     sig = {
@@ -125,6 +128,11 @@ def load():
     lib.ew_gemm_streamk_status.restype = c_int
     lib.ew_set_gemm_debug.argtypes = [c_int]
     lib.ew_set_gemm_debug.restype = None
+    if hasattr(lib, "ew_set_cu_budget"):
+        lib.ew_set_cu_budget.argtypes, lib.ew_set_cu_budget.restype = [c_int], c_int
+        lib.ew_get_cu_budget.argtypes, lib.ew_get_cu_budget.restype = [], c_int
+        lib.ew_stream_create_cu_mask.argtypes, lib.ew_stream_create_cu_mask.restype = [c_int, c_int], c_void_p
+        lib.ew_stream_destroy.argtypes, lib.ew_stream_destroy.restype = [c_void_p], c_int
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

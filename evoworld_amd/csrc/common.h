@@ -16,6 +16,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // thread-local error message (ew_last_error)
 void ew_set_error(const char* fmt, ...);
+int ew_cu_budget();                   // CUs the persistent kernels may assume (runtime.cpp; 256 unless ew_set_cu_budget changed it)
 ew_status ew_check_launch(const char* what);
 
 #define EW_REQUIRE(cond, ...)                    \

@@ -615,7 +615,8 @@ extern "C" ew_status ew_ff_geglu320_f16(const ew_ff_args* a, void* stream) {
     p.c_acc = a->c_acc; p.c_r1 = a->r1 ? a->c_r1 : 0.f; p.c_r2 = a->r2 ? a->c_r2 : 0.f;
     p.x_lo = (const int8_t*)a->x_lo; p.ln_gamma = (const f16*)a->ln_gamma; p.ln_beta = (const f16*)a->ln_beta;
     p.addvec = (const f16*)a->addvec; p.add_rpg = a->add_rows_per_group >= 1 ? a->add_rows_per_group : 1; p.ln_eps = a->ln_eps;
-    const int grid = p.n_tiles < 256 ? p.n_tiles : 256;
+    const int ncu = ew_cu_budget();                 // 256 unless the caller runs on a CU-masked stream
+    const int grid = p.n_tiles < ncu ? p.n_tiles : ncu;
 #ifdef FF_TRACE
     p.trace = g_ff_trace;
 #else

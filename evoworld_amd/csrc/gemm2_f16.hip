@@ -561,7 +561,7 @@ ew_status launch2(const GemmP& p, hipStream_t s) {
     if (ew_status st = ew_ensure_dynamic_lds((const void*)gemm2_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE, MODE, EPI>, (int)lds, attr_mask)) return st;
     const long long tiles = (long long)q.tiles_m * q.tiles_n;
     if (tiles <= 0 || tiles > 0x7fffffffLL) { ew_set_error("ew_gemm_f16: bad grid"); return EW_ERR_INVALID_ARG; }
-    int grid = (NW == 8 || BM == 256) ? 256 : 512;                   // persistent: 1 x 8-wave or 2 x 4-wave workgroups per CU (256 CUs)
+    int grid = (NW == 8 || BM == 256) ? ew_cu_budget() : 2 * ew_cu_budget();                   // persistent: 1 x 8-wave or 2 x 4-wave workgroups per CU (256 CUs)
     if (tiles < grid) grid = (int)((tiles + 7) / 8 * 8);
     snprintf(g_gemm_last_kernel, 64, "gemm2_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, BN, WAVES_M, WAVES_N, NSTAGE, MODE, EPI);
     hipLaunchKernelGGL((gemm2_kernel<BM, BN, WAVES_M, WAVES_N, NSTAGE, MODE, EPI>), dim3(grid), dim3(64 * NW), lds, s, q);

@@ -1087,7 +1087,7 @@ inline int sk_half_min_k() {
 inline bool sk_half_shape(const GemmP& p, long long tiles) {
     static const int sk_mode = getenv("EW_G3_SK") ? atoi(getenv("EW_G3_SK")) : 1;
     const int mk = sk_half_min_k();
-    return sk_mode && mk > 0 && !(p.dbg & 4) && tiles >= 8 && 2 * tiles <= 256 && (2 * tiles) % 8 == 0 && (p.K / BK) % 2 == 0 && p.K >= mk;
+    return sk_mode && mk > 0 && !(p.dbg & 4) && tiles >= 8 && 2 * tiles <= ew_cu_budget() && (2 * tiles) % 8 == 0 && (p.K / BK) % 2 == 0 && p.K >= mk;
 }
 template <int MODE, int EPI>
 inline bool sk_half_applies(const GemmP& p, long long tiles) {
@@ -1104,7 +1104,8 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
     static std::atomic<unsigned long long> attr_mask{0};                   // per (kernel instantiation, device)
     if (ew_status st = ew_ensure_dynamic_lds((const void*)gemm3_kernel<MODE, EPI>, (int)lds, attr_mask)) return st;
     const long long tiles = (long long)q.tiles_m * q.tiles_n;
-    int grid = 256;                                   // persistent: one 8-wave workgroup per CU
+    const int NCU = ew_cu_budget();                   // 256 unless the caller runs on a CU-masked stream (ew_set_cu_budget)
+    int grid = NCU;                                   // persistent: one 8-wave workgroup per CU
     if (tiles < grid) grid = (int)((tiles + 7) / 8 * 8);
     // Stream-K tail: T tiles over 256 blocks cost ceil(T/256) rounds; every C-wide output of the U-Net is 1800 / 900 / 452 tiles =
     // 7.03 / 3.52 / 1.77 rounds paid as 8 / 4 / 2.  When the loss is worth it, the last (T mod 256) + 256 tiles are cut along K
@@ -1116,16 +1117,16 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
     // GEMMs with at most two tile columns and K >= 1280 (-4 ... -8 %).  With four tile columns (level 2) the blocks of an XCD
     // are out of phase along K and stop sharing the A rows and W slices in L2: +7 ... +16 % -- left on the whole-tile schedule.
     const bool sk_shape = MODE == EW_A_CONV3X3 || (q.tiles_n <= 2 && p.K >= sk_min_k) || sk_mode == 2;
-    if (sk_mode && sk_shape && !(MODE == EW_A_DENSE && EPI == 23) && !(p.dbg & 4) && grid == 256 && tiles > 256 && tiles % 256 != 0) {
-        const long long rounds = (tiles + 255) / 256;
-        const double loss = 1.0 - (double)tiles / (256.0 * rounds);
+    if (sk_mode && sk_shape && !(MODE == EW_A_DENSE && EPI == 23) && !(p.dbg & 4) && grid == NCU && tiles > NCU && tiles % NCU != 0) {
+        const long long rounds = (tiles + NCU - 1) / NCU;
+        const double loss = 1.0 - (double)tiles / ((double)NCU * rounds);
         if (loss > 0.04) {
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
             SkWorkspace* w = sk_workspace(s, cap == hipStreamCaptureStatusNone);
             if (w) {
-                sk.dp_rounds = (int)(tiles / 256) - 1;
-                sk.tiles = (int)(tiles - 256LL * sk.dp_rounds);
+                sk.dp_rounds = (int)(tiles / NCU) - 1;
+                sk.tiles = (int)(tiles - (long long)NCU * sk.dp_rounds);
                 sk.ws = w->ws; sk.flags = w->flags; sk.epoch = sk_next_epoch(w, MODE, EPI, p);
             }
         }
@@ -1193,7 +1194,7 @@ bool EW3_NAME(ew_gemm3_wants)(const GemmP& p, hipStream_t s) {
     static const int min_m = getenv("EW_G3_MINM") ? atoi(getenv("EW_G3_MINM")) : 320;
     if (p.N % BN != 0 || p.M < min_m) return false;
     if (BN != 320 && p.N % 320 == 0) return false;                      // the 320-wide instance takes what it can
-    if ((long long)ew_cdiv(p.M, BM) * (p.N / BN) > 256LL * (ITEMS_BYTES / 16 - 4)) return false;     // work-item table of a persistent block
+    if ((long long)ew_cdiv(p.M, BM) * (p.N / BN) > (long long)ew_cu_budget() * (ITEMS_BYTES / 16 - 4)) return false;     // work-item table of a persistent block
     // GELU (CLIP's fc1) is only compiled into the plain dense variant: the erf code in every epilogue cost the conv variants
     // 11-28 spilled VGPRs (reloads inside the K loop, 4-10 % slower); anything else with GELU runs on generation 2
     if (p.act == EW_ACT_GELU && (p.mode != EW_A_DENSE || p.rowbias || p.r1 || p.r2 || p.out_lo)) return false;
@@ -1207,7 +1208,7 @@ bool EW3_NAME(ew_gemm3_wants)(const GemmP& p, hipStream_t s) {
     static const int short_rule = getenv("EW_G3_SHORT") ? atoi(getenv("EW_G3_SHORT")) : 0;     // A/B hook: 1 = gen3 also there
     if (!short_rule && p.mode == EW_A_DENSE && p.N == BN && p.K <= 1280 && (p.r1 || p.r2)) return false;
     const long long tiles = (long long)ew_cdiv(p.M, BM) * (p.N / BN);
-    if (tiles >= 200) return true;
+    if (tiles * 256 >= 200LL * ew_cu_budget()) return true;      // (200 of 256 CUs busy, scaled to the CU budget)
     // fewer tiles than CUs: generation 3 only with the half split (launch3), i.e. not for the one variant compiled without it
     const bool epi23 = p.mode == EW_A_DENSE && p.r2 && (p.r1_lo || p.r2_lo || p.out_lo);        // dispatch_epi3: <0, 16|7>
     if (epi23 || p.act == EW_ACT_GEGLU || !sk_half_shape(p, tiles)) return false;

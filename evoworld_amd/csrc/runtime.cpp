@@ -22,3 +22,27 @@ ew_status ew_check_launch(const char* what) {
 
 extern "C" const char* ew_last_error(void) { return g_err; }
 extern "C" int ew_abi_version(void) { return EW_ABI_VERSION; }
+
+// ---- CU budget of the persistent kernels + CU-masked streams (ABI 8) ----
+static int g_cu_budget = 256;
+int ew_cu_budget() { return g_cu_budget; }
+extern "C" int ew_get_cu_budget(void) { return g_cu_budget; }
+extern "C" int ew_set_cu_budget(int n) {
+    const int old = g_cu_budget;
+    if (n >= 8 && n <= 256 && n % 8 == 0) g_cu_budget = n;
+    return old;
+}
+extern "C" void* ew_stream_create_cu_mask(int first_cu, int n_cus) {
+    if (first_cu < 0 || n_cus <= 0 || first_cu + n_cus > 256) { ew_set_error("ew_stream_create_cu_mask: CU range [%d, %d) outside [0, 256)", first_cu, first_cu + n_cus); return nullptr; }
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = first_cu; c < first_cu + n_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
+    hipStream_t s = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&s, 8, mask);
+    if (e != hipSuccess) { (void)hipGetLastError(); ew_set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e)); return nullptr; }
+    return (void*)s;
+}
+extern "C" ew_status ew_stream_destroy(void* stream) {
+    const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); ew_set_error("hipStreamDestroy: %s", hipGetErrorString(e)); return EW_ERR_HIP; }
+    return EW_OK;
+}

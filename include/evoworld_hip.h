@@ -27,7 +27,7 @@ typedef int ew_status;
 #define EW_ERR_UNSUPPORTED (-2)
 #define EW_ERR_HIP (-3)
 
-#define EW_ABI_VERSION 7
+#define EW_ABI_VERSION 8
 int ew_abi_version(void);
 const char* ew_last_error(void);
 
@@ -113,6 +113,19 @@ int ew_gemm_streamk_status(void);
  * allocates it, under a mutex); call it BEFORE capturing launches into a hipGraph -- allocation is illegal during capture, and a
  * captured launch on a stream without a workspace runs the whole-tile schedule instead. */
 ew_status ew_gemm_streamk_init(void* stream);
+
+/* CU budget of the persistent kernels (ABI 8).  The persistent GEMM / feed-forward kernels launch one workgroup per CU and size their
+ * tile schedule and stream-K split from the CU count: 256 on an MI355X.  A caller that runs the library on a stream restricted to a
+ * subset of the CUs (ew_stream_create_cu_mask: two independent forwards -- the two rows of the CFG batch the reference concatenates,
+ * evoworld/pipeline/pipeline_evoworld.py:689-711 -- side by side on disjoint halves of the chip) sets the budget to that subset's size
+ * first: with more workgroups than CUs a stream-K finisher could wait for a contributor that is not resident.  Process-wide; a multiple
+ * of 8 in [8, 256].  Returns the previous value. */
+int ew_set_cu_budget(int n_cus);
+int ew_get_cu_budget(void);
+/* A HIP stream whose kernels only run on CUs [first_cu, first_cu + n_cus) of the CU-mask bit order (hipExtStreamCreateWithCUMask).
+ * Returns NULL and sets ew_last_error on failure.  Destroy with ew_stream_destroy. */
+void* ew_stream_create_cu_mask(int first_cu, int n_cus);
+ew_status ew_stream_destroy(void* stream);
 
 /* Fused GEGLU feed-forward for 320-channel tokens (ABI 5; level 0 of the U-Net: 460800 tokens per forward, 15 feed-forwards):
  *   out = c_acc * (GEGLU(x W1^T + b1) W2^T + b2 + rowbias[m / rows_per_group]) + c_r1 * r1 + c_r2 * r2
