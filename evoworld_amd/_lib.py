@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EW_LIB_PATH") or os.path.join(_HERE, "libevoworld_hip.so")   # EW_LIB_PATH: ablation builds (tools/)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # every symbol declared in include/evoworld_hip.h
 SYMBOLS = [
@@ -24,8 +24,10 @@ SYMBOLS = [
     "ew_u8_hwc_to_f32_chw", "ew_f32_chw_to_u8_hwc", "ew_blur_axis_f32", "ew_bicubic_resize_f32", "ew_vit_patchify_f16",
     "ew_attn_small_f16", "ew_quant_rows_fp8", "ew_gemm_fp8",
     "ew_set_cu_budget", "ew_get_cu_budget", "ew_stream_create_cu_mask", "ew_stream_destroy",
+    "ew_nchw_f32_to_nhwc_split_f16", "ew_euler_cfg_step_split",
 ]
-_ABI8 = {"ew_set_cu_budget", "ew_get_cu_budget", "ew_stream_create_cu_mask", "ew_stream_destroy"}
+_ABI8 = {"ew_set_cu_budget", "ew_get_cu_budget", "ew_stream_create_cu_mask", "ew_stream_destroy",
+         "ew_nchw_f32_to_nhwc_split_f16", "ew_euler_cfg_step_split"}      # (and ABI 9's two split-operand entry points)
 
 
 class GemmArgs(ctypes.Structure):
@@ -78,7 +80,7 @@ def load():
     lib.ew_last_error.restype = c_char_p
     lib.ew_gemm_last_kernel.restype = c_char_p
     lib.ew_abi_version.restype = c_int
-    if lib.ew_abi_version() != ABI_VERSION and not (ablation and lib.ew_abi_version() == 7):
+    if lib.ew_abi_version() != ABI_VERSION and not (ablation and lib.ew_abi_version() in (7, 8)):
         raise EvoWorldHipError(f"ABI mismatch: library {lib.ew_abi_version()} != binding {ABI_VERSION}")
     P, I, F, LL = c_void_p, c_int, c_float, c_longlong
     sig = {
@@ -95,6 +97,8 @@ def load():
         "ew_nchw_f32_to_nhwc_f16": [P, P, I, I, I, I, I, I, F, P],
         "ew_nhwc_f16_to_nchw_f32": [P, P, I, I, I, I, I, P],
         "ew_euler_cfg_step": [P, I, P, P, F, F, P, I, I, I, I, P],
+        "ew_nchw_f32_to_nhwc_split_f16": [P, P, I, I, I, I, I, I, I, I, F, P],
+        "ew_euler_cfg_step_split": [P, I, P, P, F, F, P, I, I, I, I, I, I, P],
         "ew_softmax_rows_f16": [P, P, P, LL, I, LL, P],
         "ew_time_conv3_f32": [P, P, P, P, I, I, I, I, P],
         "ew_plucker_embed": [P, P, P, I, I, I, P],

@@ -5,15 +5,28 @@
 
 namespace {
 
+constexpr float SPLIT_DUP_SCALE = 0.0009765625f;   // 2^-10 (evoworld_amd/unet.py SPLIT_DUP_LOG2): the duplicate block meets W_lo * 2^10, a normal fp16 number
+
+// lo_off > 0 (ABI 9, split operand): besides hi = fp16(v) at channel c_off + c the row also receives lo = fp16(v - hi) at lo_off + c_off + c and a
+// copy of hi scaled by 2^-10 at dup_off + c_off + c -- the three K blocks [x_hi | x_lo | x_hi 2^-10] that conv_in multiplies with [W_hi | W_hi | W_lo 2^10]
+// inside the 64-channel K tile it pads its 18 input channels to anyway (evoworld_amd/unet.py: conv_in with exact operands).
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, f16* __restrict__ y, int N, int C, int HW, int ldc,
-                                    int c_off, float scale) {
+                                    int c_off, float scale, int lo_off, int dup_off) {
     const long long total = (long long)N * HW;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long n = i / HW;
         const int p = (int)(i - n * HW);
         const float* xp = x + n * C * (long long)HW + p;
         f16* yp = y + i * ldc + c_off;
-        for (int c = 0; c < C; ++c) yp[c] = (f16)(scale * xp[(long long)c * HW]);
+        for (int c = 0; c < C; ++c) {
+            const float v = scale * xp[(long long)c * HW];
+            const f16 hi = (f16)v;
+            yp[c] = hi;
+            if (lo_off > 0) {
+                yp[lo_off + c] = (f16)(v - (float)hi);
+                yp[dup_off + c] = (f16)((float)hi * SPLIT_DUP_SCALE);
+            }
+        }
     }
 }
 
@@ -31,7 +44,7 @@ __global__ void nhwc_to_nchw_kernel(const f16* __restrict__ x, float* __restrict
 // one thread per (frame t, pixel): 4 latent channels
 __global__ void euler_cfg_kernel(const f16* __restrict__ eps, int ld_eps, float* __restrict__ lat,
                                  const float* __restrict__ guidance, float sigma, float sigma_next, f16* __restrict__ nxt,
-                                 int cpad, int T, int HW) {
+                                 int cpad, int T, int HW, int lo_off, int dup_off) {
     const long long total = (long long)T * HW;
     const float s2p1 = sigma * sigma + 1.0f;
     const float c_out = -sigma / sqrtf(s2p1);
@@ -43,7 +56,7 @@ __global__ void euler_cfg_kernel(const f16* __restrict__ eps, int ld_eps, float*
         const f16x4 eu = *(const f16x4*)(eps + i * ld_eps);
         const f16x4 ec = *(const f16x4*)(eps + (i + total) * ld_eps);
         const float g = guidance[t];
-        f16x4 o;
+        f16x4 o, ol, od;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float u = (float)eu[c], cn = (float)ec[c];
@@ -55,9 +68,17 @@ __global__ void euler_cfg_kernel(const f16* __restrict__ eps, int ld_eps, float*
             const float xn = x + d * dt;
             *lp = xn;
             o[c] = (f16)(xn * in_scale);                            // scale_model_input for the next step
+            ol[c] = (f16)(xn * in_scale - (float)o[c]);             // split operand (lo_off > 0): what the fp16 rounding dropped
+            od[c] = (f16)((float)o[c] * SPLIT_DUP_SCALE);
         }
         *(f16x4*)(nxt + i * cpad) = o;
         *(f16x4*)(nxt + (i + total) * cpad) = o;
+        if (lo_off > 0) {
+            *(f16x4*)(nxt + i * cpad + lo_off) = ol;
+            *(f16x4*)(nxt + (i + total) * cpad + lo_off) = ol;
+            *(f16x4*)(nxt + i * cpad + dup_off) = od;
+            *(f16x4*)(nxt + (i + total) * cpad + dup_off) = od;
+        }
     }
 }
 
@@ -153,8 +174,18 @@ extern "C" ew_status ew_nchw_f32_to_nhwc_f16(const float* x, void* y, int N, int
                                              float scale, void* stream) {
     EW_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && c_off >= 0 && c_off + C <= ldc, "ew_nchw_f32_to_nhwc_f16: bad args");
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long long)N * H * W)), dim3(256), 0, (hipStream_t)stream, x,
-                       (f16*)y, N, C, H * W, ldc, c_off, scale);
+                       (f16*)y, N, C, H * W, ldc, c_off, scale, 0, 0);
     return ew_check_launch("ew_nchw_f32_to_nhwc_f16");
+}
+
+extern "C" ew_status ew_nchw_f32_to_nhwc_split_f16(const float* x, void* y, int N, int C, int H, int W, int ldc, int c_off, int lo_off,
+                                                   int dup_off, float scale, void* stream) {
+    EW_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && c_off >= 0, "ew_nchw_f32_to_nhwc_split_f16: bad args");
+    EW_REQUIRE(lo_off >= c_off + C && dup_off >= lo_off + c_off + C && dup_off + c_off + C <= ldc,
+               "ew_nchw_f32_to_nhwc_split_f16: the three channel blocks [c_off, +C), [lo_off + c_off, +C), [dup_off + c_off, +C) must be disjoint and inside ldc=%d", ldc);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long long)N * H * W)), dim3(256), 0, (hipStream_t)stream, x,
+                       (f16*)y, N, C, H * W, ldc, c_off, scale, lo_off, dup_off);
+    return ew_check_launch("ew_nchw_f32_to_nhwc_split_f16");
 }
 
 extern "C" ew_status ew_nhwc_f16_to_nchw_f32(const void* x, float* y, int N, int C, int H, int W, int ldc, void* stream) {
@@ -170,8 +201,21 @@ extern "C" ew_status ew_euler_cfg_step(const void* eps, int ld_eps, float* laten
     EW_REQUIRE(T > 0 && h > 0 && w > 0 && ld_eps % 4 == 0 && cpad % 4 == 0 && ld_eps >= 4 && cpad >= 4, "ew_euler_cfg_step: bad shape");
     EW_REQUIRE(sigma > 0.f, "ew_euler_cfg_step: sigma must be > 0");
     hipLaunchKernelGGL(euler_cfg_kernel, dim3(grid_for((long long)T * h * w)), dim3(256), 0, (hipStream_t)stream,
-                       (const f16*)eps, ld_eps, latents, guidance, sigma, sigma_next, (f16*)next_in, cpad, T, h * w);
+                       (const f16*)eps, ld_eps, latents, guidance, sigma, sigma_next, (f16*)next_in, cpad, T, h * w, 0, 0);
     return ew_check_launch("ew_euler_cfg_step");
+}
+
+extern "C" ew_status ew_euler_cfg_step_split(const void* eps, int ld_eps, float* latents, const float* guidance, float sigma,
+                                             float sigma_next, void* next_in, int cpad, int lo_off, int dup_off, int T, int h, int w,
+                                             void* stream) {
+    EW_REQUIRE(eps && latents && guidance && next_in, "ew_euler_cfg_step_split: null pointer");
+    EW_REQUIRE(T > 0 && h > 0 && w > 0 && ld_eps % 4 == 0 && cpad % 4 == 0 && ld_eps >= 4 && cpad >= 4, "ew_euler_cfg_step_split: bad shape");
+    EW_REQUIRE(lo_off >= 4 && lo_off % 4 == 0 && dup_off >= lo_off + 4 && dup_off % 4 == 0 && dup_off + 4 <= cpad,
+               "ew_euler_cfg_step_split: lo_off / dup_off must be multiples of 4 with [0,4), [lo_off,+4), [dup_off,+4) disjoint inside cpad=%d", cpad);
+    EW_REQUIRE(sigma > 0.f, "ew_euler_cfg_step_split: sigma must be > 0");
+    hipLaunchKernelGGL(euler_cfg_kernel, dim3(grid_for((long long)T * h * w)), dim3(256), 0, (hipStream_t)stream,
+                       (const f16*)eps, ld_eps, latents, guidance, sigma, sigma_next, (f16*)next_in, cpad, T, h * w, lo_off, dup_off);
+    return ew_check_launch("ew_euler_cfg_step_split");
 }
 
 extern "C" ew_status ew_softmax_rows_f16(const void* hi, const void* lo, void* out, long long rows, int cols, long long ld,

@@ -273,10 +273,16 @@ def time_conv3(x, w, bias):
     return y
 
 
-def nchw_f32_to_nhwc_f16(x, y, ldc, c_off=0, scale=1.0):
+def nchw_f32_to_nhwc_f16(x, y, ldc, c_off=0, scale=1.0, split=None):
+    """split = (lo_off, dup_off): the row also receives fp16(v - hi) at lo_off + c_off + c and hi again at dup_off + c_off + c
+    (ew_nchw_f32_to_nhwc_split_f16: the [x_hi | x_lo | x_hi] A operand of a conv_in packed [W_hi | W_hi | W_lo])."""
     lib = _lib.load()
     _req(x, torch.float32, "x"); _req(y, torch.float16, "y")
     N, C, H, W = x.shape
+    if split:
+        _lib.check(lib.ew_nchw_f32_to_nhwc_split_f16(_ptr(x), _ptr(y), N, C, H, W, ldc, c_off, split[0], split[1], scale, _stream()),
+                   "ew_nchw_f32_to_nhwc_split_f16")
+        return y
     _lib.check(lib.ew_nchw_f32_to_nhwc_f16(_ptr(x), _ptr(y), N, C, H, W, ldc, c_off, scale, _stream()),
                "ew_nchw_f32_to_nhwc_f16")
     return y
@@ -290,9 +296,13 @@ def nhwc_f16_to_nchw_f32(x, N, C, H, W, ldc):
     return y
 
 
-def euler_cfg_step(eps, ld_eps, latents, guidance, sigma, sigma_next, next_in, cpad, T, h, w):
+def euler_cfg_step(eps, ld_eps, latents, guidance, sigma, sigma_next, next_in, cpad, T, h, w, split=None):
     lib = _lib.load()
     _req(latents, torch.float32, "latents"); _req(guidance, torch.float32, "guidance")
+    if split:
+        _lib.check(lib.ew_euler_cfg_step_split(_ptr(eps), ld_eps, _ptr(latents), _ptr(guidance), float(sigma), float(sigma_next),
+                                               _ptr(next_in), cpad, split[0], split[1], T, h, w, _stream()), "ew_euler_cfg_step_split")
+        return
     _lib.check(lib.ew_euler_cfg_step(_ptr(eps), ld_eps, _ptr(latents), _ptr(guidance), float(sigma), float(sigma_next),
                                      _ptr(next_in), cpad, T, h, w, _stream()), "ew_euler_cfg_step")
 

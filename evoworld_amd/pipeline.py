@@ -213,11 +213,13 @@ class StableVideoDiffusionPipeline:
         ts = self.scheduler.timesteps
         lat = latents[0].to(device=dev, dtype=torch.float32).contiguous().clone()
         x_in = torch.zeros(2 * T * h * w, CPAD_IN, dtype=torch.float16, device=dev)
+        # the model-input row as the U-Net wants it: plain fp16 channels, or (default) the split operand [x_hi | x_lo | x_hi 2^-10] of its conv_in
+        split = getattr(self.unet, "in_split", None)
         ops.nchw_f32_to_nhwc_f16(conditional_latents.to(device=dev, dtype=torch.float32).reshape(2 * T, ncond, h, w).contiguous(),
-                                 x_in, CPAD_IN, c_off=4)
+                                 x_in, CPAD_IN, c_off=4, split=split)
         s0 = float(sig[0])
         for half in range(2):  # latents duplicated on both CFG rows, scale_model_input for step 0 (:691-692)
-            ops.nchw_f32_to_nhwc_f16(lat, x_in[half * T * h * w:], CPAD_IN, c_off=0, scale=1.0 / (s0 * s0 + 1.0) ** 0.5)
+            ops.nchw_f32_to_nhwc_f16(lat, x_in[half * T * h * w:], CPAD_IN, c_off=0, scale=1.0 / (s0 * s0 + 1.0) ** 0.5, split=split)
         guidance = guidance.to(device=dev, dtype=torch.float32).contiguous()
         ehs = image_embeddings.to(dev)
         ids = added_time_ids.to(dev)
@@ -225,7 +227,7 @@ class StableVideoDiffusionPipeline:
         if grp is None:
             for i in range(num_inference_steps):
                 eps = self.unet.forward_nhwc(x_in, ts[i], ehs, ids, 2, T, h, w)
-                ops.euler_cfg_step(eps, eps.shape[-1], lat, guidance, float(sig[i]), float(sig[i + 1]), x_in, CPAD_IN, T, h, w)
+                ops.euler_cfg_step(eps, eps.shape[-1], lat, guidance, float(sig[i]), float(sig[i + 1]), x_in, CPAD_IN, T, h, w, split=split)
                 if callback is not None:
                     callback(i, ts[i], lat)
         else:
@@ -241,7 +243,7 @@ class StableVideoDiffusionPipeline:
                         eps_all = torch.zeros(2, rows, eps_r.shape[-1], dtype=eps_r.dtype, device=dev)
                     eps_all[r].copy_(eps_r)
                 grp.all_gather_rows(eps_all, eps_r)       # eps_r: the forward's own output buffer (not a view of eps_all)
-                ops.euler_cfg_step(eps_all, eps_all.shape[-1], lat, guidance, float(sig[i]), float(sig[i + 1]), x_in, CPAD_IN, T, h, w)
+                ops.euler_cfg_step(eps_all, eps_all.shape[-1], lat, guidance, float(sig[i]), float(sig[i + 1]), x_in, CPAD_IN, T, h, w, split=split)
                 if callback is not None:
                     callback(i, ts[i], lat)
         ops.streamk_check()      # synchronises; raises if any stream-K hand-over of the loop timed out (wrong tile)

@@ -40,6 +40,14 @@ DEFAULT_CONFIG = dict(  # evoworld/trainer/unet_plucker.py:69-94 with in_channel
     transformer_layers_per_block=1, num_attention_heads=(5, 10, 20, 20), num_frames=25)
 
 CPAD_IN = 64  # conv_in input channels padded to one 64-wide K tile
+SPLIT_DUP_LOG2 = 10  # conv_in with exact operands (round 5): the duplicate block of the input row holds x_hi * 2^-10 and its weight rows W_lo * 2^10,
+#                      so that W_lo (~2^-12 |W|) is a NORMAL fp16 number whatever the MFMA does with denormals (csrc/elementwise.hip uses the same constant)
+
+
+def split_in_offsets(in_channels):
+    """(lo_off, dup_off) of the split model-input row [x_hi | x_lo | x_hi 2^-10] inside CPAD_IN channels, or None when three blocks do not fit."""
+    s = (in_channels + 3) // 4 * 4
+    return (s, 2 * s) if 3 * s <= CPAD_IN else None
 
 
 def _pad64(c):
@@ -237,6 +245,17 @@ class UNetSpatioTemporalConditionModel:
         # the 1.18 GB GEGLU intermediate of each of the 15 level-0 feed-forwards out of HBM (-35 GB per forward) and measures
         # -1.0 ms per forward in place (A/B in one process); mode 2 is +9 ms (profiles/r03_e_*)
         self.fused_ff = int(os.environ.get("EW_FUSED_FF", "1"))
+        # Round 5: fp16 operand rounding removed where it is (nearly) free.  An fp32 checkpoint (what the reference runs, unified_loop_consistency.py:188)
+        # rounded to fp16 once costs as much squared distance to the fp32 oracle as all activation operands together, and per layer group (tiny
+        # config, tests/analysis_fp16_floor.py --per-group) conv_in + conv_out + the level-0 proj_in / proj_out carry ~40 % of it for < 1 % of the flops:
+        #   * conv_in: BOTH operands split inside the 64-channel K tile its 18 input channels are padded to anyway -- the model-input row is
+        #     [x_hi | x_lo | x_hi 2^-10] (in_split; written by ew_nchw_f32_to_nhwc_split_f16 / ew_euler_cfg_step_split) against weight rows
+        #     [W_hi | W_hi | W_lo 2^10]: zero extra MFMA work;
+        #   * conv_out and the proj_in / proj_out GEMMs of the 320-channel transformers: W = W_hi + W_lo as a second K block over the SAME A
+        #     operand (the dual-source addressing mode of the skip concat: a2 = a), K doubles on ~14 small launches.
+        # EW_SPLIT_OPERANDS=0 restores single-rounded operands everywhere (A/B).
+        self.split_operands = os.environ.get("EW_SPLIT_OPERANDS", "1") != "0"
+        self.in_split = split_in_offsets(cfg["in_channels"]) if self.split_operands else None
         self._pos_cache = {}
         for hd, c in zip(cfg["num_attention_heads"], cfg["block_out_channels"]):
             if c // hd != 64:
@@ -353,6 +372,16 @@ class UNetSpatioTemporalConditionModel:
         def convt(k):              # [O,I,3,1,1] -> [O, K], K = [I/64][3][64]
             return ops.pack_conv_weight(f32(k + ".weight"))
 
+        def hi_lo(w):              # fp32 weight -> (fp16-representable part, remainder), both fp32
+            w_hi = w.to(torch.float16).to(torch.float32)
+            return w_hi, w - w_hi
+
+        def lin2(k, c):            # [O, I] -> [O, 2 I] = [W_hi | W_lo] for the level-0 projections (a2 = a), plain fp16 otherwise
+            w = f32(k + ".weight")
+            if not (self.split_operands and c == self._cfg["block_out_channels"][0]):
+                return h(w)
+            return h(torch.cat(hi_lo(w), dim=1))
+
         def geglu(k):              # interleave value/gate rows in blocks of 16 (see ew_gemm_f16)
             w, b = f32(k + ".weight"), f32(k + ".bias")
             n = w.shape[0] // 2
@@ -391,8 +420,8 @@ class UNetSpatioTemporalConditionModel:
             d = {}
             c = t.ch
             d["ng"], d["nb"] = h(f32(t.p + ".norm.weight")), h(f32(t.p + ".norm.bias"))
-            d["piw"], d["pib"] = h(f32(t.p + ".proj_in.weight")), h(f32(t.p + ".proj_in.bias"))
-            d["pow"], d["pob"] = h(f32(t.p + ".proj_out.weight")), h(f32(t.p + ".proj_out.bias"))
+            d["piw"], d["pib"] = lin2(t.p + ".proj_in", c), h(f32(t.p + ".proj_in.bias"))
+            d["pow"], d["pob"] = lin2(t.p + ".proj_out", c), h(f32(t.p + ".proj_out.bias"))
             d["mix"] = float(torch.sigmoid(f32(t.p + ".time_mixer.mix_factor")).item())
             d["pe1w"], d["pe1b"] = h(f32(t.p + ".time_pos_embed.linear_1.weight")), h(f32(t.p + ".time_pos_embed.linear_1.bias"))
             d["pe2w"], d["pe2b"] = h(f32(t.p + ".time_pos_embed.linear_2.weight")), h(f32(t.p + ".time_pos_embed.linear_2.bias"))
@@ -436,8 +465,18 @@ class UNetSpatioTemporalConditionModel:
         for blk in self.arch.ups:
             if blk.up:
                 W[blk.up.p] = (conv3(blk.up.p), h(f32(blk.up.p + ".bias")))
-        W["conv_in"] = (conv3("conv_in", CPAD_IN), h(f32("conv_in.bias")))
-        W["conv_out"] = (conv3("conv_out"), h(f32("conv_out.bias")))
+        if self.in_split:
+            w_hi, w_lo = hi_lo(f32("conv_in.weight"))
+            ci, (lo_off, dup_off) = w_hi.shape[1], self.in_split
+            wp = torch.zeros(w_hi.shape[0], CPAD_IN, 3, 3, dtype=torch.float32, device=dev)
+            wp[:, :ci], wp[:, lo_off:lo_off + ci], wp[:, dup_off:dup_off + ci] = w_hi, w_hi, w_lo * float(2 ** SPLIT_DUP_LOG2)
+            W["conv_in"] = (ops.pack_conv_weight(wp), h(f32("conv_in.bias")))
+        else:
+            W["conv_in"] = (conv3("conv_in", CPAD_IN), h(f32("conv_in.bias")))
+        if self.split_operands:     # [W_hi | W_lo] over the input channels: the second block reads the same tensor again (a2 = a)
+            W["conv_out"] = (ops.pack_conv_weight(torch.cat(hi_lo(f32("conv_out.weight")), dim=1)), h(f32("conv_out.bias")))
+        else:
+            W["conv_out"] = (conv3("conv_out"), h(f32("conv_out.bias")))
         W["no_g"], W["no_b"] = h(f32("conv_norm_out.weight")), h(f32("conv_norm_out.bias"))
         W["te1w"], W["te1b"] = h(f32("time_embedding.linear_1.weight")), h(f32("time_embedding.linear_1.bias"))
         W["ae1w"], W["ae1b"] = h(f32("add_embedding.linear_1.weight")), h(f32("add_embedding.linear_1.bias"))
@@ -463,6 +502,13 @@ class UNetSpatioTemporalConditionModel:
         M = B * T * P
         out = self._res(M, w.shape[0], x.device) if res_out else torch.empty(M, w.shape[0], dtype=torch.float16, device=x.device)
         return ops.gemm(x, w, out, M=M, N=w.shape[0], c1=C, lda=C, bias=b, mode=A_CONVT3, tconv=(B, T, P), **kw)
+
+    def _lin2(self, x, w, b, out, **kw):
+        """Linear whose weight may be packed [W_hi | W_lo] (twice the input width): the second K block reads x again (a2 = a)."""
+        C = x.shape[-1]
+        if w.shape[1] == C:
+            return ops.linear(x, w, b, out=out, **kw)
+        return ops.gemm(x, w, out, M=x.shape[0], N=w.shape[0], c1=C, lda=C, a2=x, c2=C, lda2=C, bias=b, **kw)
 
     def _resblock(self, r, xs, tembs, B, T, H, W_):
         """SpatioTemporalResBlock = ResnetBlock2D -> TemporalResnetBlock -> AlphaBlender.
@@ -518,7 +564,7 @@ class UNetSpatioTemporalConditionModel:
         cv_s = cvecs[:, self._cv_off[(t.p, "s")]:]
         cv_t = cvecs[:, self._cv_off[(t.p, "t")]:]
         hn = ops.groupnorm([x], d["ng"], d["nb"], N, S, 1e-6, False, pool=self._gn_pool)
-        h = ops.linear(hn, d["piw"], d["pib"], out=self._res(rows, C, dev, head=True))
+        h = self._lin2(hn, d["piw"], d["pib"], self._res(rows, C, dev, head=True))
         # --- spatial BasicTransformerBlock ---
         n1 = ops.layernorm(h, d["s_norm1g"], d["s_norm1b"])
         if self.qkv_fp8:
@@ -592,11 +638,12 @@ class UNetSpatioTemporalConditionModel:
             ffh = ops.linear(n3, d["t_f1w"], d["t_f1b"], act=ACT_GEGLU)
             hb = ops.linear(ffh, d["t_f2w"], d["t_f2b"], c_acc=1.0 - a, r1=hm, ld_r1=C, c_r1=1.0 - a, r2=h, ld_r2=C, c_r2=a)
             del ffh
-        return ops.linear(hb, d["pow"], d["pob"], out=self._res(rows, C, dev), r1=x, ld_r1=C)
+        return self._lin2(hb, d["pow"], d["pob"], self._res(rows, C, dev), r1=x, ld_r1=C)
 
     # ---------------- forward ----------------
     def forward_nhwc(self, x, timestep, encoder_hidden_states, added_time_ids, B, T, H, W_, taps=None):
-        """x: fp16 [B*T*H*W, 64] channels-last (18 real channels, zero padded) -> fp16 [B*T*H*W, 4]."""
+        """x: fp16 [B*T*H*W, 64] channels-last (18 real channels, zero padded; with `self.in_split` = (lo_off, dup_off) the row is the split
+        operand [x_hi | x_lo | x_hi 2^-10] that ops.nchw_f32_to_nhwc_f16(split=...) / ops.euler_cfg_step(split=...) write) -> fp16 [B*T*H*W, 4]."""
         cfg, Wt = self._cfg, self.w
         dev = x.device
         ops.streamk_init()      # stream-K workspace of this (device, stream): allocated here, never inside a launch / graph capture
@@ -655,7 +702,8 @@ class UNetSpatioTemporalConditionModel:
             if taps is not None:
                 taps[f"up{bi}"] = (h.float(), H, W_)
         hn = ops.groupnorm([h], Wt["no_g"], Wt["no_b"], N, H * W_, 1e-5, True, pool=self._gn_pool)
-        return self._conv3x3(hn, None, *Wt["conv_out"], N, H, W_, H, W_)
+        wco, bco = Wt["conv_out"]       # packed [W_hi | W_lo] (twice the input channels): the second block reads hn again
+        return self._conv3x3(hn, hn if wco.shape[1] == 2 * 9 * hn.shape[-1] else None, wco, bco, N, H, W_, H, W_)
 
     @torch.no_grad()
     def __call__(self, sample, timestep, encoder_hidden_states, added_time_ids, return_dict=True, taps=None):
@@ -668,7 +716,7 @@ class UNetSpatioTemporalConditionModel:
             raise ValueError("latent height/width must be multiples of 8 (three stride-2 levels)")
         x = torch.zeros(B * T * H * W_, CPAD_IN, dtype=torch.float16, device=self.device)
         ops.nchw_f32_to_nhwc_f16(sample.to(device=self.device, dtype=torch.float32).reshape(B * T, C, H, W_).contiguous(),
-                                 x, CPAD_IN)
+                                 x, CPAD_IN, split=self.in_split)
         eps = self.forward_nhwc(x, timestep, encoder_hidden_states, added_time_ids, B, T, H, W_, taps=taps)
         oc = self._cfg["out_channels"]
         out = ops.nhwc_f16_to_nchw_f32(eps, B * T, oc, H, W_, oc).reshape(B, T, oc, H, W_)

@@ -27,7 +27,7 @@ typedef int ew_status;
 #define EW_ERR_UNSUPPORTED (-2)
 #define EW_ERR_HIP (-3)
 
-#define EW_ABI_VERSION 8
+#define EW_ABI_VERSION 9
 int ew_abi_version(void);
 const char* ew_last_error(void);
 
@@ -232,6 +232,15 @@ ew_status ew_attn_temporal_f16(const void* q, const void* k, const void* v, void
 ew_status ew_nchw_f32_to_nhwc_f16(const float* x, void* y, int N, int C, int H, int W, int ldc, int c_off, float scale,
                                   void* stream);
 ew_status ew_nhwc_f16_to_nchw_f32(const void* x, float* y, int N, int C, int H, int W, int ldc, void* stream);
+/* Split-operand form (ABI 9): with v = scale * x[n,c,h,w] and hi = fp16(v) the row receives THREE channel blocks,
+ *   y[.., c_off + c] = hi,   y[.., lo_off + c_off + c] = fp16(v - hi),   y[.., dup_off + c_off + c] = fp16(hi * 2^-10),
+ * i.e. the A operand [x_hi | x_lo | x_hi 2^-10] of a conv_in whose weight rows are packed [W_hi | W_hi | W_lo 2^10] (the power of two keeps
+ * W_lo ~ 2^-12 |W| a normal fp16 number): x W is then formed to ~2^-21
+ * instead of 2^-11 in BOTH operands at no MFMA cost, because conv_in pads its 18 input channels to one 64-channel K tile anyway
+ * (3 * 20 <= 64).  The reference's conv_in runs on fp32 operands (weight_dtype = torch.float32, unified_loop_consistency.py:188;
+ * evoworld/trainer/unet_plucker.py:131-136); its two fp16 roundings were 12-15 % each of the build's squared distance to the fp32 oracle. */
+ew_status ew_nchw_f32_to_nhwc_split_f16(const float* x, void* y, int N, int C, int H, int W, int ldc, int c_off, int lo_off,
+                                        int dup_off, float scale, void* stream);
 
 /* Fused denoise-step glue: CFG combine + Euler (v-prediction) step + scale_model_input + concat for the next
  * step.  eps: fp16 NHWC [2*T, h, w, ld_eps] (rows [0,T) uncond, [T,2T) cond; first 4 channels);
@@ -240,6 +249,11 @@ ew_status ew_nhwc_f16_to_nchw_f32(const void* x, float* y, int N, int C, int H, 
  * Replaces evoworld/pipeline/pipeline_evoworld.py:691-695,709-714 + EulerDiscreteScheduler.step/scale_model_input. */
 ew_status ew_euler_cfg_step(const void* eps, int ld_eps, float* latents, const float* guidance, float sigma,
                             float sigma_next, void* next_in, int cpad, int T, int h, int w, void* stream);
+/* Same step writing the next model input as a split operand (ABI 9; see ew_nchw_f32_to_nhwc_split_f16): channels [0,4) = hi,
+ * [lo_off, lo_off+4) = fp16(value - hi), [dup_off, dup_off+4) = fp16(hi * 2^-10), for both CFG rows.  lo_off, dup_off: multiples of 4. */
+ew_status ew_euler_cfg_step_split(const void* eps, int ld_eps, float* latents, const float* guidance, float sigma,
+                                  float sigma_next, void* next_in, int cpad, int lo_off, int dup_off, int T, int h, int w,
+                                  void* stream);
 
 /* Row softmax for the VAE's single-head attention (AutoencoderKLTemporalDecoder mid blocks, head_dim 512: diffusers
  * Attention with upcast_softmax; pipeline_evoworld.py:307-328,358-385 via vae.encode / vae.decode): the [S,S] score matrix

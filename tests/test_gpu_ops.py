@@ -353,6 +353,64 @@ def test_layout_roundtrip(ops):
     assert torch.equal(back.cpu(), ref.float().reshape(3, 8, 16, 18).permute(0, 3, 1, 2))
 
 
+def test_layout_split_operand(ops):
+    """ew_nchw_f32_to_nhwc_split_f16 (ABI 9): [x_hi | x_lo | x_hi 2^-10] channel blocks of the split model-input row, bit-exact."""
+    x = rnd(3, 14, 8, 16, seed=4) * 3.0
+    y = torch.full((3 * 8 * 16, 64), 5.0, dtype=torch.float16, device=DEV)
+    ops.nchw_f32_to_nhwc_f16(x.to(DEV), y, 64, c_off=4, scale=0.5, split=(20, 40))
+    v = (0.5 * x).permute(0, 2, 3, 1).reshape(-1, 14)
+    hi = v.half()
+    lo = (v - hi.float()).half()
+    dup = (hi.float() * 2.0 ** -10).half()
+    y = y.cpu()
+    assert torch.equal(y[:, 4:18], hi) and torch.equal(y[:, 24:38], lo) and torch.equal(y[:, 44:58], dup)
+    keep = torch.ones(64, dtype=torch.bool)
+    keep[4:18] = keep[24:38] = keep[44:58] = False
+    assert (y[:, keep] == 5.0).all()
+    # hi + lo carries ~21 bits of the fp32 value
+    assert rel_l2(hi.float() + lo.float(), v) < 2e-6
+    with pytest.raises(Exception):
+        ops.nchw_f32_to_nhwc_f16(x.to(DEV), torch.zeros(3 * 8 * 16, 64, dtype=torch.float16, device=DEV), 64, c_off=4, split=(16, 40))   # blocks overlap
+
+
+def test_euler_cfg_step_split(ops):
+    """ew_euler_cfg_step_split: same step; the next model input as hi / lo / hi 2^-10 blocks on both CFG rows, other channels untouched."""
+    T, h, w = 5, 8, 16
+    eps = rnd(2 * T * h * w, 4, seed=1).half().to(DEV)
+    lat = (rnd(T, 4, h, w, seed=2) * 300).to(DEV)
+    lat_b = lat.clone()
+    guid = torch.linspace(1, 3, T).to(DEV)
+    nxt = torch.full((2 * T * h * w, 64), 7.0, dtype=torch.float16, device=DEV)
+    nxt_b = nxt.clone()
+    sigma, sigma_next = 421.56912, 322.45367
+    ops.euler_cfg_step(eps, 4, lat, guid, sigma, sigma_next, nxt, 64, T, h, w, split=(20, 40))
+    ops.euler_cfg_step(eps, 4, lat_b, guid, sigma, sigma_next, nxt_b, 64, T, h, w)
+    assert torch.equal(lat, lat_b) and torch.equal(nxt[:, :4], nxt_b[:, :4])
+    v = (lat.double() / (sigma_next ** 2 + 1) ** 0.5).permute(0, 2, 3, 1).reshape(T * h * w, 4)
+    got = nxt.reshape(2, T * h * w, 64)
+    assert torch.equal(got[0], got[1])
+    hi, lo, dup = got[0, :, :4], got[0, :, 20:24], got[0, :, 40:44]
+    assert torch.equal(dup, (hi.float() * 2.0 ** -10).half())
+    assert rel_l2((hi.double() + lo.double()).cpu(), v.cpu()) < 3e-6          # fp32 arithmetic of the kernel, ~21 bits kept
+    keep = torch.ones(64, dtype=torch.bool)
+    keep[0:4] = keep[20:24] = keep[40:44] = False
+    assert (got[:, :, keep] == 7.0).all()
+
+
+def test_mfma_keeps_fp16_denormal_operands(ops):
+    """W = W_hi + W_lo as a second K block (conv_out, level-0 proj_in / proj_out): W_lo ~ 2^-12 |W| is a SUBNORMAL fp16 number for typical
+    weights, so the split only works if the MFMA does not flush fp16 denormal inputs.  Checked through the GEMM itself."""
+    M, N, K = 512, 320, 64
+    a = rnd(M, K, seed=1).half().to(DEV)
+    w = (rnd(N, K, seed=2) * 2e-6).half().to(DEV)                 # every element subnormal (|w| < 6.1e-5), ~30 quanta of 5.96e-8
+    assert (w.float().abs() < 6.0e-5).all() and (w != 0).float().mean() > 0.9
+    got = ops.linear(a, w, c_acc=4096.0).float().cpu()          # (the epilogue scale lifts the products out of fp16's own subnormal range)
+    ref = (a.float().cpu() @ w.float().cpu().T) * 4096.0
+    e = rel_l2(got, ref)
+    print(f"GEMM with subnormal fp16 weights: rel-L2 {e:.2e} (flushed inputs would give 1.0)")
+    assert e < 1e-3
+
+
 def test_euler_cfg_step(ops):
     T, h, w = 5, 8, 16
     eps = rnd(2 * T * h * w, 4, seed=1).half().to(DEV)

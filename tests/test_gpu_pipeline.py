@@ -296,8 +296,13 @@ def test_full_size_clip_vs_oracle():
     if ck and os.path.exists(ck):
         st = torch.load(ck)
         assert st["steps"] == steps
+        assert st.get("fp32w", fp32w) == fp32w, "checkpoint was recorded under the other weight protocol"
         start, lat_start = st["done"], st["lat"]
         print(f"full-size clip: oracle resumed after step {start}", flush=True)
+        # a checkpoint written by tools/oracle_full_clip_cpu.py (the oracle loop run on host cores elsewhere: same seeds, same inputs) carries
+        # fp32 copies of a subset of the steps' latents: the curve at those steps
+        for i, lat in sorted(st.get("trace", {}).items()):
+            print(f"full-size clip step {i:2d}/{steps}: rel-L2 {rel_l2(got[i - 1], lat):.3e}  (oracle latents from the checkpoint)", flush=True)
     stop = int(os.environ.get("EW_FULL_PARITY_STOP", "0")) or None
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
