@@ -38,6 +38,13 @@
 #ifndef EW_ATTN_VW64
 #define EW_ATTN_VW64 1       /* round 5: V^T tile written as four ds_write_b64 straight from the loaded registers instead of eight v_mov + two ds_write_b128 */
 #endif
+#ifdef EW_ATTN_TRACE       /* instrumented build (make attn_trace; tools/experiments/exp47_attn_trace.py): s_memtime stamps of one workgroup, 6 per 64-key tile and wave */
+#define ATTN_TRACE_ARG , unsigned long long* trace
+#define ATTN_STAMP(k) do { if (trace && blockIdx.x == 4001 && lane == 0 && j < 256) trace[((size_t)j * 4 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ATTN_TRACE_ARG
+#define ATTN_STAMP(k) do {} while (0)
+#endif
 namespace {
 
 __device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
@@ -55,7 +62,7 @@ template <bool PRE>
 __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatial_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                                const f16* __restrict__ vt, f16* __restrict__ o, int S,
                                                                int heads, int ld_qk, long long ld_vt, int ld_o, float sl2,
-                                                               int n_qtiles) {
+                                                               int n_qtiles ATTN_TRACE_ARG) {
     __shared__ __attribute__((aligned(16))) char smem[32768];  // 2 x { K tile [64 keys][64 d] | V^T tile [64 d][64 keys] }
     char* const kl = smem;
     char* const vl = smem + 8192;
@@ -176,6 +183,7 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
         const int key0 = j * 64;
         const char* kb = kl + BUF * 16384;
         const char* vb = vl + BUF * 16384;
+        ATTN_STAMP(0);
         if (j + 1 < nt) {
             kp_run += (long long)64 * ld_qk;
             vp_run += 64;
@@ -204,6 +212,7 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
 #if EW_ATTN_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
+        ATTN_STAMP(1);
         // ---- mask the ragged last tile ----
         if (key0 + 64 > S) {
 #pragma unroll
@@ -331,6 +340,7 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
             }
             l_run += lt;
         }
+        ATTN_STAMP(2);
         // ---- O^T += V^T P^T ----
 #if EW_ATTN_PRIO == 2
         __builtin_amdgcn_s_setprio(1);
@@ -346,9 +356,12 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
 #if EW_ATTN_PRIO == 2
         __builtin_amdgcn_s_setprio(0);
 #endif
+        ATTN_STAMP(3);
         // double-buffered tiles: the other buffer was last read in iteration j-1 (every wave passed that barrier)
         if (j + 1 < nt) write_tile(std::integral_constant<int, BUF ^ 1>{});
+        ATTN_STAMP(4);
         __syncthreads();
+        ATTN_STAMP(5);
     };
     if constexpr (LAZY) {
         tile_step(0, std::integral_constant<int, 0>{}, std::true_type{});
@@ -642,6 +655,13 @@ __global__ __launch_bounds__(256) void attn_temporal64_kernel(const f16* __restr
 
 }  // namespace
 
+#ifdef EW_ATTN_TRACE
+static unsigned long long* g_attn_trace = nullptr;
+extern "C" void ew_attn_set_trace(void* buf) { g_attn_trace = (unsigned long long*)buf; }
+#define ATTN_TRACE_PASS , g_attn_trace
+#else
+#define ATTN_TRACE_PASS
+#endif
 static ew_status attn_spatial_launch(const void* q, const void* k, const void* vt, void* o, int n_seq, int S, int heads, int ld_qk,
                                      long long ld_vt, int ld_o, float scale, bool pre, void* stream, const char* name) {
     EW_REQUIRE(q && k && vt && o, "%s: null pointer", name);
@@ -653,11 +673,11 @@ static ew_status attn_spatial_launch(const void* q, const void* k, const void* v
     EW_REQUIRE(nblk < 0x7fffffffLL, "%s: grid too large", name);
     if (pre)
         hipLaunchKernelGGL(attn_spatial_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const f16*)q,
-                           (const f16*)k, (const f16*)vt, (f16*)o, S, heads, ld_qk, ld_vt, ld_o, 1.0f, n_qtiles);
+                           (const f16*)k, (const f16*)vt, (f16*)o, S, heads, ld_qk, ld_vt, ld_o, 1.0f, n_qtiles ATTN_TRACE_PASS);
     else
         hipLaunchKernelGGL(attn_spatial_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const f16*)q,
                            (const f16*)k, (const f16*)vt, (f16*)o, S, heads, ld_qk, ld_vt, ld_o,
-                           scale * 1.4426950408889634f, n_qtiles);
+                           scale * 1.4426950408889634f, n_qtiles ATTN_TRACE_PASS);
     return ew_check_launch(name);
 }
 

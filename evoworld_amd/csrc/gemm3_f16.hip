@@ -63,6 +63,22 @@ constexpr int ITEMS_BYTES = 8192;                                      // work-i
 constexpr int PD = EW_G3_DIST;                                         // W fragments are read PD steps ahead of their MFMAs (ring of 4)
 constexpr int BAR_STEP = NSTEP - 1 - PD;                               // barrier after the step that issues the tile's last read
 
+// ---- halo-slab A loader of the stride-1 3x3 convs (round 5; MODE == EW_A_CONV3X3H, chosen by the dispatcher, not part of the ABI) ----
+// The plain conv mode stages one 256-row x 64-channel A tile per (channel chunk, tap): 9 x 32 KB per chunk, every tap re-fetching the same
+// input lines through L2 (measured: 99 GB of L2-miss traffic per forward for ~10 GB of unique conv operands).  For a tile of 256 consecutive
+// output pixels = 256 / W whole image rows (W = 64 / 128 / 256) the three taps of one kernel ROW (ky) read the same pixels shifted by -1 / 0 / +1:
+// they are served from ONE slab = the tile's image rows with a zero pixel before and after each row (W + 2 slab rows per image row, the
+// left / right padding of the conv), staged once per (chunk, ky) = 33 KB instead of 3 x 32 KB.  Tap kx of output row r (image row q = r / W
+// of the tile) reads slab row r + 2 q + kx: a pure address shift of the A fragment reads, no per-read masking; rows above / below the image
+// (ky) are zero-page rows at staging time, exactly as in the plain mode.  K order, operand values and the MFMA sequence are unchanged:
+// results are bit-identical to the plain mode's.  LDS: two slabs (by kernel-row group) + two W stages (by K-tile) + the item table = 154 KB.
+constexpr int EW_A_CONV3X3H = 3;
+constexpr int SLAB_P = BM / 8 + 1;                                     // 33 one-KB pieces = 264 slab rows >= 256 + 2 * (256 / W) for W >= 64
+constexpr int SLAB_BYTES = SLAB_P * 1024;
+constexpr int GAH = (SLAB_P + NW - 1) / NW;                            // 5 slab pieces per wave (the fifth on wave 0 only)
+constexpr int W_BYTES = BN * 128;                                      // one K-tile of W
+constexpr int HALO_LDS = 2 * SLAB_BYTES + 2 * W_BYTES;                 // (+ ITEMS_BYTES)
+
 // Tile id -> (tm, tn).  Ids are consumed in XCD-contiguous chunks of 32 (one per CU of an XCD at a time), so 32 consecutive ids
 // should form a 2-D block that shares as many operand rows as possible in that XCD's 4 MB L2.  With more than BAND tile
 // columns a plain "tn fastest" order makes a chunk one M-tile x 32 N-tiles: every chunk streams 32 different W slices (the
@@ -99,6 +115,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
 #ifndef EW_G3_RESLDS
 #define EW_G3_RESLDS 1          /* round 5: residual operands of the DIRECT epilogue come in through the LDS (see the RES_LDS epilogue below) */
 #endif
+    constexpr bool HALO = MODE == EW_A_CONV3X3H;
+    static_assert(!HALO || (EPI & ~16) == 1, "halo-slab loader: built for the row-bias / split-output epilogue (conv1 of the resblocks) only");
     constexpr bool RB_INIT = bool(EW_G3_RB_INIT) && bool(EW_G3_BIAS_INIT) && DIRECT && (EPI & 1);
     // DIRECT variants with residual operands: the epilogue takes both LDS stages as landing zones of its residual tiles (LDS-DMA, 8 KB per
     // wave, operand and row fragment: 60-120 KB in flight per CU instead of the ~24 KB two VGPR operand sets allowed), so the first
@@ -141,7 +159,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     // The items (tile id, first K-tile, end K-tile) go into a small LDS table behind the two stages: the loader and the MFMA
     // stream each read one entry per tile.  (Computing them in place -- a branchy expression inside the loader lambda -- kept
     // hipcc from promoting the lambdas' captured state to registers: 600 bytes of scratch per lane.)
-    int* const items = (int*)(smem + 2 * STAGE);
+    int* const items = (int*)(smem + (HALO ? HALO_LDS : 2 * STAGE));
+    // W stage s of the halo layout, as a base the stage-relative offsets (b_rd: A_BYTES + ...) can be added to
+    auto stage_base = [&](int st) __attribute__((always_inline)) -> char* { return HALO ? smem + (2 * SLAB_BYTES - A_BYTES) + st * W_BYTES : smem + st * STAGE; };
     for (int w = threadIdx.x; w < n_sk + n_dp; w += 64 * NW) {
         int id, k0 = 0, k1 = nk;
         if (w < n_sk) {
@@ -167,10 +187,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     const int slot = (lane & 7) ^ srow;
 
     // ---------------- loader state (one K-tile ahead of the MFMA stream, across output tiles) ----------------
-    constexpr int NTAP = MODE == EW_A_CONV3X3 ? 9 : (MODE == EW_A_CONVT3 ? 3 : 1);
+    constexpr int NTAP = (MODE == EW_A_CONV3X3 || HALO) ? 9 : (MODE == EW_A_CONVT3 ? 3 : 1);
+    constexpr int GAX = HALO ? GAH : GA;   // A-side DMA pieces per wave and staging
+    constexpr int NPX = GAX + GB;
     int ld_w = 0, ld_kt = 0, ld_k1 = 0, ld_tap = 0, ld_cc = 0;   // ld_kt == ld_k1: the next stage_begin opens work item ld_w
-    int a_ctr[GA];                         // centre-tap pixel (row) index in the source tensors
-    int a_mask[GA];                        // bits 0..8 tap validity, bits 16..27 upsample (dy,dx) codes
+    int a_ctr[GAX];                        // centre-tap pixel (row) index in the source tensors (HALO: (pixel of the slab row << 3) | kernel-row validity bits)
+    int a_mask[HALO ? 1 : GA];             // bits 0..8 tap validity, bits 16..27 upsample (dy,dx) codes
+    int ld_sb = 0;                         // HALO: slab buffer of the kernel-row group staged last
     const f16* b_ptr0 = p.w;               // W row of this lane's first piece (+ its 16-byte slot); piece j adds j*NW*8 rows
 
     auto loader_new_tile = [&](const int id) __attribute__((always_inline)) {
@@ -182,8 +205,24 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
         const int srow_o = lane_o >> 3, slot_o = (lane_o & 7) ^ srow_o;
+        if constexpr (HALO) {
+            // slab row s = (wave + 8 i) * 8 + srow  ->  image row q = s / (W + 2) of the tile, slab column xs = s % (W + 2): columns 0 and W + 1 are
+            // the zero pixels beside the row, column xs the pixel m0 + q W + xs - 1
+            const int wp = p.w_in + 2, nq = BM / p.w_in;
 #pragma unroll
-        for (int i = 0; i < GA; ++i) {
+            for (int i = 0; i < GAH; ++i) {
+                const int sr = (wave + NW * i) * 8 + srow_o;
+                const int q = sr / wp, xs = sr - q * wp;
+                int b = m0 + q * p.w_in + xs - 1;
+                const bool ok = q < nq && xs >= 1 && xs <= p.w_in && b < p.M;
+                b = ok ? b : 0;
+                const int yb = (b / p.w_in) % p.h_in;
+                const int mk = ok ? ((yb >= 1 ? 1 : 0) | 2 | (yb + 1 < p.h_in ? 4 : 0)) : 0;      // kernel rows ky = 0 / 1 / 2 stay inside the image
+                a_ctr[i] = (b << 3) | mk;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (HALO ? 0 : GA); ++i) {
             int m = m0 + (wave + NW * i) * 8 + srow_o;
             m = m < p.M ? m : p.M - 1;
             int ctr, mask = 1, dcode = 0;
@@ -239,8 +278,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     int st_tap = 0, st_ld = 0, st_ch = 0;
     size_t st_koff = 0;
     char* st_buf = smem;
+    char* st_sbuf = smem;                  // HALO: slab buffer being staged
+    bool st_slab = false;                  // HALO: this staging opens a kernel-row group (first K-tile of a work item, or kx == 0): the slab goes with it
+    int st_ky = 0;
     auto stage_begin = [&](char* buf) __attribute__((always_inline)) {
+        bool opened = false;
         if (ld_kt == ld_k1) {
+            opened = true;
             int id, k0;
             EW3_GET_ITEM(ld_w, id, k0, ld_k1);
             ++ld_w;
@@ -260,6 +304,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
         int dpix = 0;                                                       // wave-uniform tap delta in pixels
         if constexpr (MODE == EW_A_CONV3X3) dpix = (st_tap / 3 - 1) * p.w_in + (st_tap % 3 - 1);
         else if constexpr (MODE == EW_A_CONVT3) dpix = (st_tap - 1) * p.tP;
+        else if constexpr (HALO) {
+            st_ky = st_tap / 3;
+            st_slab = opened || st_tap == st_ky * 3;
+            if (st_slab) { ld_sb ^= 1; st_sbuf = smem + ld_sb * SLAB_BYTES; }
+            dpix = (st_ky - 1) * p.w_in;
+        }
         st_dl = (long long)dpix * st_ld + st_ch;
         st_koff = (size_t)ld_kt * BK;
         // K order: channel-chunk major, tap minor (the taps of a 64-channel chunk re-hit the same lines in L2 / TCP)
@@ -267,6 +317,20 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
         ++ld_kt;
     };
     auto stage_piece = [&](int k) __attribute__((always_inline)) {     // k is a compile-time constant after unrolling
+        if constexpr (HALO) {
+            if (k < GAH) {
+                if (st_slab && (k < GAH - 1 || wave + NW * k < SLAB_P)) {
+                    const int c = a_ctr[k];
+                    const f16* src = st_base + ((long long)(c >> 3) * st_ld + (st_dl + slot * 8));
+                    src = ((c >> st_ky) & 1) ? src : st_zp;
+                    glds16(src, st_sbuf + (wave + NW * k) * 1024);
+                }
+            } else {
+                const int j = k - GAH;
+                glds16(b_ptr0 + (size_t)(j * NW * 8) * p.K + st_koff, st_buf + A_BYTES + (wave + NW * j) * 1024);
+            }
+            return;
+        }
         if (k < GA) {
             const int i = k;
             const f16* src = st_base + ((long long)a_ctr[i] * st_ld + (st_dl + slot * 8));
@@ -300,6 +364,17 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
         a_rd[kh] = (wm * WM + frow) * 128 + so;
         b_rd[kh] = A_BYTES + (wn * WN + frow) * 128 + so;
     }
+
+    // HALO: the A fragment of row fragment i, k-half kh and kernel column kx sits at slab row wm*64 + i*16 + frow + 2 q + kx (q = image row of the
+    // wave's 64 rows inside the tile: W >= 64), 16-byte slot ((kh*4 + fks) ^ (row & 7)); recomputed per K-tile from the thread id (kx changes with
+    // every K-tile; nothing lane-constant is kept live across the stream)
+    int cur_tap = 0, cur_sb = 0;           // consumer side: tap (ky*3 + kx) and slab buffer of the K-tile at stream position v
+    auto halo_ard = [&](const int kx, const int kh) __attribute__((always_inline)) {
+        int lane_o = tid & 63;
+        asm volatile("" : "+v"(lane_o));
+        const int rr = (lane_o & 15) + kx + 2 * ((wm * WM) / p.w_in);
+        return (wm * WM + rr) * 128 + (((kh * 4 + (lane_o >> 4)) ^ (rr & 7)) << 4);
+    };
 
     f32x4 acc[FM][FN];
     // Accumulators of a work item start as the bias of its tile column (every row fragment the same 4 columns per lane and
@@ -350,29 +425,49 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     f16x8 bfr[4];                          // W fragment ring: step t consumes bfr[t & 3]
 
     // ---------------- prologue ----------------
-    stage_begin(smem);
+    stage_begin(stage_base(0));
 #pragma unroll
-    for (int k = 0; k < NP; ++k) stage_piece(k);
+    for (int k = 0; k < NPX; ++k) stage_piece(k);
     int staged = 1;
     EW3_WAIT_VM0();
     EW3_FENCE();
     __builtin_amdgcn_s_barrier();
     EW3_FENCE();
-#pragma unroll
-    for (int i = 0; i < FM; ++i) af[0][i] = EW3_LDS(smem + a_rd[0] + i * 2048);
-#pragma unroll
-    for (int j = 0; j < PD; ++j) bfr[j] = EW3_LDS(smem + b_rd[0] + j * 2048);
-
     int cur_w = 0, cur_id, cur_kt, cur_k1;
     EW3_GET_ITEM(0, cur_id, cur_kt, cur_k1);
     cur_w = 1;
+    if constexpr (HALO) {
+        cur_tap = cur_kt - (cur_kt / NTAP) * NTAP;
+        cur_sb = 1;                                    // the loader's first slab went to buffer 1
+        const int a0 = halo_ard(cur_tap - (cur_tap / 3) * 3, 0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[0][i] = EW3_LDS(smem + SLAB_BYTES + a0 + i * 2048);
+    } else {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[0][i] = EW3_LDS(smem + a_rd[0] + i * 2048);
+    }
+#pragma unroll
+    for (int j = 0; j < PD; ++j) bfr[j] = EW3_LDS(stage_base(0) + b_rd[0] + j * 2048);
+
     init_acc(cur_id, cur_kt);
     bool cur_tail = cur_kt > 0;                      // stream-K: this item is the tail of a tile another block finishes
     int s_cur = 0;                                   // ring slot of stream position v
     for (int v = 0; v < V; ++v) {
-        const char* cur = smem + s_cur * STAGE;
-        char* nxt = smem + (s_cur ^ 1) * STAGE;
+        const char* cur = stage_base(s_cur);
+        char* nxt = stage_base(s_cur ^ 1);
         const bool tile_end = cur_kt == cur_k1 - 1;
+        // HALO: where this K-tile's second-half A fragments and the next K-tile's first-half ones sit
+        const char* slab_c = smem + cur_sb * SLAB_BYTES;
+        const char* slab_n = slab_c;
+        int nxt_tap = cur_tap + 1, nxt_sb = cur_sb, a1c = 0, a0n = 0;
+        if constexpr (HALO) {
+            a1c = halo_ard(cur_tap - (cur_tap / 3) * 3, 1);
+            if (nxt_tap == NTAP) nxt_tap = 0;
+            const int nkx = nxt_tap - (nxt_tap / 3) * 3;
+            if (nkx == 0) nxt_sb ^= 1;                 // the next K-tile opens a kernel-row group: its slab is in the other buffer
+            slab_n = smem + nxt_sb * SLAB_BYTES;
+            a0n = halo_ard(nkx, 0);
+        }
         const bool pend = staged < V;                // K-tile v+1 exists: stage it into the other slot during steps 0..8
         // RES_LDS: at a tile end both stages belong to the epilogue's residual tiles; K-tile v+1 (the first of the next work item)
         // is staged inside the epilogue instead (tile-end section below)
@@ -386,7 +481,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                 const int kh2 = (t + PD) / FN, j2 = (t + PD) - kh2 * FN;
                 bfr[(t + PD) & 3] = EW3_LDS(cur + b_rd[kh2] + j2 * 2048);
             }
-            if (t < FM) af[1][t] = EW3_LDS(cur + a_rd[1] + t * 2048);
+            if (t < FM) af[1][t] = HALO ? EW3_LDS(slab_c + a1c + t * 2048) : EW3_LDS(cur + a_rd[1] + t * 2048);
             if (t >= NSTEP - PD) {
                 // first fragments of the next K-tile -- except at a tile end: the epilogue needs the registers (160 live
                 // accumulators), so they are read after it instead
@@ -394,12 +489,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                     bfr[(t + PD) & 3] = EW3_LDS(nxt + b_rd[0] + (t + PD - NSTEP) * 2048);
                     if (t >= NSTEP - 2) {
                         const int i0 = (t - (NSTEP - 2)) * 2;
-                        af[0][i0] = EW3_LDS(nxt + a_rd[0] + i0 * 2048);
-                        af[0][i0 + 1] = EW3_LDS(nxt + a_rd[0] + (i0 + 1) * 2048);
+                        af[0][i0] = HALO ? EW3_LDS(slab_n + a0n + i0 * 2048) : EW3_LDS(nxt + a_rd[0] + i0 * 2048);
+                        af[0][i0 + 1] = HALO ? EW3_LDS(slab_n + a0n + (i0 + 1) * 2048) : EW3_LDS(nxt + a_rd[0] + (i0 + 1) * 2048);
                     }
                 }
             }
-            if (t < NP) {
+            if (t < NPX) {
                 if (pend_now) stage_piece(t);
             }
             EW3_PIN();
@@ -422,6 +517,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
             }
         }
         s_cur ^= 1;
+        const int old_sb = cur_sb;
+        if constexpr (HALO) { cur_tap = nxt_tap; cur_sb = nxt_sb; }        // (overridden below at a work-item end)
         if (++cur_kt == cur_k1) {
             // ------------------------- end of work item: epilogue of output tile cur_id (or stream-K hand-over) -------------------------
             const int id = cur_id;
@@ -430,6 +527,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
             if (cur_w < n_sk + n_dp) {
                 EW3_GET_ITEM(cur_w, cur_id, cur_kt, cur_k1);
                 cur_tail = cur_kt > 0;                       // never true past item 0; kept general
+            }
+            if constexpr (HALO) {
+                // a work item always opens with its own slab (the loader flipped buffers for it, whatever the tap it starts at)
+                cur_sb = old_sb ^ 1;
+                cur_tap = cur_kt - (cur_kt / NTAP) * NTAP;
             }
             ++cur_w;
             int tm, tn;
@@ -759,15 +861,17 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                 int lane_o = tid & 63;
                 asm volatile("" : "+v"(lane_o));
                 const f32x4* wsp = (const f32x4*)sk.ws + (size_t)(seq0 + 1) * (FM * FN * 64 * NW) + wave * 64 + lane_o;
-                char* const stg = smem + (s_cur ^ 1) * STAGE + wave * 8192;
+                // (HALO: the released W stage holds 40 KB: four pieces per wave and round instead of eight)
+                constexpr int SKU = HALO ? 4 : 8;
+                char* const stg = stage_base(s_cur ^ 1) + (HALO ? A_BYTES : 0) + wave * (SKU * 1024);
 #pragma unroll
-                for (int b0 = 0; b0 < FM * FN; b0 += 8) {
+                for (int b0 = 0; b0 < FM * FN; b0 += SKU) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) glds16((const f16*)(wsp + (b0 + u) * (64 * NW)), stg + u * 1024);
+                    for (int u = 0; u < SKU; ++u) glds16((const f16*)(wsp + (b0 + u) * (64 * NW)), stg + u * 1024);
                     EW3_WAIT_VM0();
                     EW3_FENCE();
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < SKU; ++u) {
                         const int f = b0 + u;
                         acc[f / FN][f % FN] += *(const f32x4*)(stg + u * 1024 + lane_o * 16);
                     }
@@ -982,9 +1086,16 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
             init_acc(cur_id, cur_kt);            // (cur_* already describe the NEXT item; past the last one the values are never used)
             // first fragments of the next tile's first K-tile (skipped at steps 18-19 of this position)
             {
-                const char* c2 = smem + s_cur * STAGE;
+                const char* c2 = stage_base(s_cur);
+                if constexpr (HALO) {
+                    const char* sl = smem + cur_sb * SLAB_BYTES;
+                    const int a0 = halo_ard(cur_tap - (cur_tap / 3) * 3, 0);
 #pragma unroll
-                for (int i = 0; i < FM; ++i) af[0][i] = EW3_LDS(c2 + a_rd[0] + i * 2048);
+                    for (int i = 0; i < FM; ++i) af[0][i] = EW3_LDS(sl + a0 + i * 2048);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) af[0][i] = EW3_LDS(c2 + a_rd[0] + i * 2048);
+                }
 #pragma unroll
                 for (int j = 0; j < PD; ++j) bfr[j] = EW3_LDS(c2 + b_rd[0] + j * 2048);
             }
@@ -1100,7 +1211,7 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
     q.tiles_m = ew_cdiv(p.M, BM);
     q.tiles_n = p.N / BN;
     q.band = ((long long)p.N * p.K * 2 > 3LL * 1024 * 1024) ? 4 : 0;
-    const size_t lds = 2 * STAGE + ITEMS_BYTES;
+    const size_t lds = (MODE == EW_A_CONV3X3H ? HALO_LDS : 2 * STAGE) + ITEMS_BYTES;
     static std::atomic<unsigned long long> attr_mask{0};                   // per (kernel instantiation, device)
     if (ew_status st = ew_ensure_dynamic_lds((const void*)gemm3_kernel<MODE, EPI>, (int)lds, attr_mask)) return st;
     const long long tiles = (long long)q.tiles_m * q.tiles_n;
@@ -1116,7 +1227,7 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
     // Where it pays (A/B per shape on the U-Net's problems, same box): 3x3 convs at every level (-6 ... -10 %), dense / temporal
     // GEMMs with at most two tile columns and K >= 1280 (-4 ... -8 %).  With four tile columns (level 2) the blocks of an XCD
     // are out of phase along K and stop sharing the A rows and W slices in L2: +7 ... +16 % -- left on the whole-tile schedule.
-    const bool sk_shape = MODE == EW_A_CONV3X3 || (q.tiles_n <= 2 && p.K >= sk_min_k) || sk_mode == 2;
+    const bool sk_shape = MODE == EW_A_CONV3X3 || MODE == EW_A_CONV3X3H || (q.tiles_n <= 2 && p.K >= sk_min_k) || sk_mode == 2;
     if (sk_mode && sk_shape && !(MODE == EW_A_DENSE && EPI == 23) && !(p.dbg & 4) && grid == NCU && tiles > NCU && tiles % NCU != 0) {
         const long long rounds = (tiles + NCU - 1) / NCU;
         const double loss = 1.0 - (double)tiles / ((double)NCU * rounds);
@@ -1151,6 +1262,14 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
     return ew_check_launch("ew_gemm_f16(gen3)");
 }
 
+// halo-slab loader (MODE EW_A_CONV3X3H): stride-1 "same" 3x3 convs whose 256-row tiles are whole image rows of 64 / 128 / 256 pixels
+// (levels 0 and 1 of the U-Net).  EW_G3_HALO=0 (or ew_set_gemm_debug bit 3) keeps the plain per-tap loader (A/B hook; results are bit-identical either way).
+inline bool halo_ok(const GemmP& p) {
+    static const int on = getenv("EW_G3_HALO") ? atoi(getenv("EW_G3_HALO")) : 0;   // off: measured at +-0 in time and in FETCH_SIZE (profiles/r05_f_*)
+    return on && !(p.dbg & 8) && p.stride == 1 && !p.upsample && p.conv_shift == 0 && p.h_in == p.h_out && p.w_in == p.w_out &&
+           (p.w_in == 64 || p.w_in == 128 || p.w_in == 256) && (long long)p.n_img * p.h_in * p.w_in == p.M && p.M < (1 << 28);
+}
+
 // operand sets that occur in the U-Net (evoworld_amd/unet.py); any other mask runs on the smallest compiled superset
 template <int MODE>
 ew_status dispatch_epi3(const GemmP& p, hipStream_t s) {
@@ -1161,7 +1280,12 @@ ew_status dispatch_epi3(const GemmP& p, hipStream_t s) {
     const int mask = (p.rowbias ? 1 : 0) | (p.r1 ? 2 : 0) | (p.r2 ? 4 : 0);
     if (p.r1_lo || p.r2_lo || p.out_lo) {           // split-fp16 residual stream: general path with the lo companions
         // no residual operand (round 5): the row-bias enters through the accumulators' initial value, the epilogue only converts and stores
-        if (EW_G3_RB_INIT && (mask & 6) == 0) return launch3<MODE, 16 | 1>(p, s);
+        if (EW_G3_RB_INIT && (mask & 6) == 0) {
+            if constexpr (MODE == EW_A_CONV3X3) {
+                if (halo_ok(p)) return launch3<EW_A_CONV3X3H, 16 | 1>(p, s);
+            }
+            return launch3<MODE, 16 | 1>(p, s);
+        }
         if constexpr (MODE == EW_A_DENSE) {
             if ((mask & 4) == 0) return launch3<MODE, 16 | 3>(p, s);
             return launch3<MODE, 16 | 7>(p, s);

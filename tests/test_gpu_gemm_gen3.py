@@ -139,6 +139,46 @@ def test_conv3x3(ops, lib, N, C, c2, O, H, W, stride, up, eps):
     assert rel_l2(g3.float().cpu(), g1.float().cpu()) < 1e-3
 
 
+@pytest.mark.parametrize("N,C,c2,O,H,W", [(50, 64, 0, 320, 24, 128),       # level-0 geometry (W = 128: two image rows per tile), one chunk
+                                         (9, 128, 64, 320, 72, 128),      # dual source, three chunks, 324 tiles: whole-tile rounds + stream-K tail
+                                         (13, 128, 0, 640, 37, 64),       # level-1 geometry (W = 64: four image rows per tile), two tile columns, ragged last row tile
+                                         (8, 64, 0, 320, 25, 256)])       # one image row per tile, fewer tiles than CUs (no stream-K)
+def test_conv3x3_halo_slab_loader(ops, lib, N, C, c2, O, H, W):
+    """Round 5: the halo-slab A loader (gemm3 MODE 3: one slab per (channel chunk, kernel row) serves the three kernel columns) -- taken for
+    stride-1 convs with row-bias + split output whose tiles are whole image rows -- against torch AND bit for bit against the plain per-tap
+    loader (ew_set_gemm_debug bit 3): same K order, same operand values, same MFMA sequence."""
+    x1, x2 = rnd(N, C, H, W, seed=1), (rnd(N, c2, H, W, seed=7) if c2 else None)
+    w, b = rnd(O, C + c2, 3, 3, seed=2) / math.sqrt(9 * (C + c2)), rnd(O, seed=3)
+    xin = (torch.cat([x1, x2], 1) if c2 else x1).half().float()
+    ref = F.conv2d(xin.to(DEV), w.half().float().to(DEV), b.half().float().to(DEV), padding=1)
+    M = N * H * W
+    rpg = 2 * H * W
+    rb = rnd(M // rpg + 1, O + 32, seed=4).half().to(DEV)
+    a1, a2 = _nhwc(x1), (_nhwc(x2) if c2 else None)
+    wp, bh = _pack3(w), b.half().to(DEV)
+    lib.ew_set_gemm_debug.argtypes = [ctypes.c_int]
+
+    def run(dbg):
+        out = ops.Res.empty(M, O, DEV, True)
+        out.hi.fill_(7.0); out.lo.fill_(3)
+        lib.ew_set_gemm_debug(dbg)
+        try:
+            ops.gemm(a1, wp, out, M=M, N=O, c1=C, lda=C, a2=a2, c2=c2, lda2=c2, bias=bh, rowbias=rb, ld_rowbias=O + 32,
+                     rows_per_group=rpg, mode=ops.A_CONV3X3, conv=(N, H, W, H, W, 1, 0))
+            name = lib.ew_gemm_last_kernel().decode()
+        finally:
+            lib.ew_set_gemm_debug(0)
+        torch.cuda.synchronize()
+        return out, name
+    halo, kh = run(0)
+    plain, kp = run(8)
+    assert kh == "gemm3_kernel<3, 17>" and kp == "gemm3_kernel<1, 17>", (kh, kp)
+    assert torch.equal(halo.hi, plain.hi) and torch.equal(halo.lo, plain.lo)
+    y = ref.permute(0, 2, 3, 1).reshape(M, O) + rb.float()[torch.arange(M, device=DEV) // rpg, :O]
+    assert rel_l2(halo.float().cpu(), y.cpu()) < 3e-4
+    ops.streamk_check()
+
+
 def test_conv_temporal(ops, lib):
     B, T, P, C, O = 2, 25, 1031, 64, 320
     x = rnd(B, T, P, C, seed=1)
