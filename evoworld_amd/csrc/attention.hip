@@ -35,6 +35,12 @@
 #define EW_ATTN_LAZYMAX 1    /* round 5 (log2 form only): no per-tile max in the hot path -- a tile's row sum (which the normaliser needs anyway) tells whether
                                 any of its exponentials left the safe range; only then, and on a sequence's first tile, the max chain + rescale run */
 #endif
+#ifndef EW_ATTN_EARLY_WRITE
+#define EW_ATTN_EARLY_WRITE 1   /* round 5: the s_memtime anatomy (profiles/r05_g_exp47_attn_cycle_anatomy.txt) showed 650 of a tile's 3600 clocks per wave waiting for the
+                                   NEXT tile's K / V loads (requested at the top of the tile, stored to LDS at its end: ~0.8 of a tile period in flight).  The other LDS buffer
+                                   is free from the barrier that opens the tile, so tile j+1 is stored at the TOP of tile j and the registers take tile j+2 at once: a full
+                                   tile period in flight, no extra registers, no extra LDS */
+#endif
 #ifndef EW_ATTN_VW64
 #define EW_ATTN_VW64 1       /* round 5: V^T tile written as four ds_write_b64 straight from the loaded registers instead of eight v_mov + two ds_write_b128 */
 #endif
@@ -169,6 +175,13 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
     const int nt = (S + 63) / 64;
     load_tile(0);
     write_tile(std::integral_constant<int, 0>{});
+#if EW_ATTN_EARLY_WRITE
+    if (nt > 1) {                       // tile 1 waits in the registers; tile_step(0) stores it
+        kp_run += (long long)64 * ld_qk;
+        vp_run += 64;
+        if (128 <= S) load_tile_full(); else load_tile(64);
+    }
+#endif
     __syncthreads();
     // One 64-key tile; the LDS buffer it reads (BUF) and the one it refills (BUF ^ 1) are compile-time constants: the loop is
     // unrolled by two below, so buffer selection costs no VALU (it used to be eight xors on the fragment offsets plus address
@@ -184,11 +197,22 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
         const char* kb = kl + BUF * 16384;
         const char* vb = vl + BUF * 16384;
         ATTN_STAMP(0);
+#if EW_ATTN_EARLY_WRITE
+        // the other buffer was last read in iteration j-1 and every wave has passed that barrier: tile j+1 (requested a whole tile ago) goes in now,
+        // and the registers are free for tile j+2
+        if (j + 1 < nt) write_tile(std::integral_constant<int, BUF ^ 1>{});
+        if (j + 2 < nt) {
+            kp_run += (long long)64 * ld_qk;
+            vp_run += 64;
+            if (key0 + 192 <= S) load_tile_full(); else load_tile(key0 + 128);
+        }
+#else
         if (j + 1 < nt) {
             kp_run += (long long)64 * ld_qk;
             vp_run += 64;
             if (key0 + 128 <= S) load_tile_full(); else load_tile(key0 + 64);
         }
+#endif
 
         // ---- S^T = K Q^T : two 32-key blocks ----
 #if EW_ATTN_PRIO
@@ -357,8 +381,10 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
         __builtin_amdgcn_s_setprio(0);
 #endif
         ATTN_STAMP(3);
+#if !EW_ATTN_EARLY_WRITE
         // double-buffered tiles: the other buffer was last read in iteration j-1 (every wave passed that barrier)
         if (j + 1 < nt) write_tile(std::integral_constant<int, BUF ^ 1>{});
+#endif
         ATTN_STAMP(4);
         __syncthreads();
         ATTN_STAMP(5);

@@ -1263,10 +1263,12 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
 }
 
 // halo-slab loader (MODE EW_A_CONV3X3H): stride-1 "same" 3x3 convs whose 256-row tiles are whole image rows of 64 / 128 / 256 pixels
-// (levels 0 and 1 of the U-Net).  EW_G3_HALO=0 (or ew_set_gemm_debug bit 3) keeps the plain per-tap loader (A/B hook; results are bit-identical either way).
+// (levels 0 and 1 of the U-Net).  OFF by default (round 5: forward +-0, FETCH_SIZE unchanged -- the three column taps of the plain loader already hit in
+// cache; profiles/r05_f_halo_slab_*): EW_G3_HALO=1 or ew_set_gemm_debug bit 4 switches it on, bit 3 forces the plain per-tap loader; results are
+// bit-identical either way (tests/test_gpu_gemm_gen3.py::test_conv3x3_halo_slab_loader).
 inline bool halo_ok(const GemmP& p) {
     static const int on = getenv("EW_G3_HALO") ? atoi(getenv("EW_G3_HALO")) : 0;   // off: measured at +-0 in time and in FETCH_SIZE (profiles/r05_f_*)
-    return on && !(p.dbg & 8) && p.stride == 1 && !p.upsample && p.conv_shift == 0 && p.h_in == p.h_out && p.w_in == p.w_out &&
+    return (on || (p.dbg & 16)) && !(p.dbg & 8) && p.stride == 1 && !p.upsample && p.conv_shift == 0 && p.h_in == p.h_out && p.w_in == p.w_out &&
            (p.w_in == 64 || p.w_in == 128 || p.w_in == 256) && (long long)p.n_img * p.h_in * p.w_in == p.M && p.M < (1 << 28);
 }
 

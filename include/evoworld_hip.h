@@ -101,8 +101,8 @@ int ew_get_gemm_generation(void);
 /* Debug aid for measurement tools (bench.py): rocprof-style name of the kernel variant the last ew_gemm_f16 call on this
    thread's library instance launched, e.g. "gemm3_kernel<0, 8>".  Not part of the reference surface. */
 const char* ew_gemm_last_kernel(void);
-void ew_set_gemm_debug(int flags);   /* measurement-only switches (bit0: skip stores, bit1: skip epilogue, bit2: no stream-K tail, bit3: plain per-tap loader
-                                        instead of the halo-slab loader of the stride-1 3x3 convs -- same results bit for bit); 0 = normal */
+void ew_set_gemm_debug(int flags);   /* measurement-only switches (bit0: skip stores, bit1: skip epilogue, bit2: no stream-K tail, bit3 / bit4: force the plain per-tap loader /
+                                        the halo-slab loader (an experiment, off by default) of the stride-1 3x3 convs -- same results bit for bit); 0 = normal */
 /* Generation 3 splits the last round of output tiles along K over its 256 persistent workgroups when whole-tile rounds would
  * leave > 4 % of the chip idle (stream-K tail: fp32 partial accumulators handed over through a library-owned uncached
  * workspace, one per (device, stream), allocated on first use: 84 MB + 67 MB for the 256-wide instance).  Deterministic: the

@@ -144,9 +144,9 @@ def test_conv3x3(ops, lib, N, C, c2, O, H, W, stride, up, eps):
                                          (13, 128, 0, 640, 37, 64),       # level-1 geometry (W = 64: four image rows per tile), two tile columns, ragged last row tile
                                          (8, 64, 0, 320, 25, 256)])       # one image row per tile, fewer tiles than CUs (no stream-K)
 def test_conv3x3_halo_slab_loader(ops, lib, N, C, c2, O, H, W):
-    """Round 5: the halo-slab A loader (gemm3 MODE 3: one slab per (channel chunk, kernel row) serves the three kernel columns) -- taken for
-    stride-1 convs with row-bias + split output whose tiles are whole image rows -- against torch AND bit for bit against the plain per-tap
-    loader (ew_set_gemm_debug bit 3): same K order, same operand values, same MFMA sequence."""
+    """Round 5: the halo-slab A loader (gemm3 MODE 3: one slab per (channel chunk, kernel row) serves the three kernel columns; an experiment,
+    off by default: ew_set_gemm_debug bit 4 / EW_G3_HALO=1) for stride-1 convs with row-bias + split output whose tiles are whole image rows --
+    against torch AND bit for bit against the plain per-tap loader (bit 3): same K order, same operand values, same MFMA sequence."""
     x1, x2 = rnd(N, C, H, W, seed=1), (rnd(N, c2, H, W, seed=7) if c2 else None)
     w, b = rnd(O, C + c2, 3, 3, seed=2) / math.sqrt(9 * (C + c2)), rnd(O, seed=3)
     xin = (torch.cat([x1, x2], 1) if c2 else x1).half().float()
@@ -170,7 +170,7 @@ def test_conv3x3_halo_slab_loader(ops, lib, N, C, c2, O, H, W):
             lib.ew_set_gemm_debug(0)
         torch.cuda.synchronize()
         return out, name
-    halo, kh = run(0)
+    halo, kh = run(16)
     plain, kp = run(8)
     assert kh == "gemm3_kernel<3, 17>" and kp == "gemm3_kernel<1, 17>", (kh, kp)
     assert torch.equal(halo.hi, plain.hi) and torch.equal(halo.lo, plain.lo)
