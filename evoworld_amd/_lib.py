@@ -26,8 +26,9 @@ SYMBOLS = [
     "ew_set_cu_budget", "ew_get_cu_budget", "ew_stream_create_cu_mask", "ew_stream_destroy",
     "ew_nchw_f32_to_nhwc_split_f16", "ew_euler_cfg_step_split",
 ]
-_ABI8 = {"ew_set_cu_budget", "ew_get_cu_budget", "ew_stream_create_cu_mask", "ew_stream_destroy",
-         "ew_nchw_f32_to_nhwc_split_f16", "ew_euler_cfg_step_split"}      # (and ABI 9's two split-operand entry points)
+# entry points newer than ABI 7: an older build of the library loaded for an A/B (EW_LIB_PATH, tools/ab_lib.sh) may lack them
+_NEWER_THAN_ABI7 = {"ew_set_cu_budget", "ew_get_cu_budget", "ew_stream_create_cu_mask", "ew_stream_destroy",      # ABI 8
+                    "ew_nchw_f32_to_nhwc_split_f16", "ew_euler_cfg_step_split"}                                     # ABI 9
 
 
 class GemmArgs(ctypes.Structure):
@@ -73,9 +74,9 @@ def load():
             f"{LIB_PATH} not found: build it with `make -C evoworld_amd/csrc` (hipcc --offload-arch=gfx950). "
             "evoworld_amd has no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
-    ablation = bool(os.environ.get("EW_LIB_PATH"))          # A/B against an older build of the library (tools/ab_lib.sh): ABI 7 is accepted there
+    ablation = bool(os.environ.get("EW_LIB_PATH"))          # A/B against an older build of the library (tools/ab_lib.sh): ABI 7 / 8 are accepted there
     for s in SYMBOLS:
-        if not hasattr(lib, s) and not (ablation and s in _ABI8):
+        if not hasattr(lib, s) and not (ablation and s in _NEWER_THAN_ABI7):
             raise EvoWorldHipError(f"{LIB_PATH} does not export {s}")
     lib.ew_last_error.restype = c_char_p
     lib.ew_gemm_last_kernel.restype = c_char_p
@@ -138,6 +139,8 @@ def load():
         lib.ew_stream_create_cu_mask.argtypes, lib.ew_stream_create_cu_mask.restype = [c_int, c_int], c_void_p
         lib.ew_stream_destroy.argtypes, lib.ew_stream_destroy.restype = [c_void_p], c_int
     for name, argtypes in sig.items():
+        if ablation and name in _NEWER_THAN_ABI7 and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = c_int

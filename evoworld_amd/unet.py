@@ -50,6 +50,33 @@ def split_in_offsets(in_channels):
     return (s, 2 * s) if 3 * s <= CPAD_IN else None
 
 
+def hi_lo(w):
+    """fp32 tensor -> (its fp16-representable part, the remainder), both fp32: w == hi + lo exactly."""
+    w_hi = w.to(torch.float16).to(torch.float32)
+    return w_hi, w - w_hi
+
+
+def split_conv_in_weight(w, in_split):
+    """conv_in weight [O, I, 3, 3] fp32 -> fp32 [O, CPAD_IN, 3, 3] whose input-channel blocks [0, I) | [lo_off, +I) | [dup_off, +I) hold
+    W_hi | W_hi | W_lo 2^10: against the row [x_hi | x_lo | x_hi 2^-10] the conv forms x_hi W_hi + x_lo W_hi + x_hi W_lo = x W - x_lo W_lo."""
+    w_hi, w_lo = hi_lo(w)
+    ci, (lo_off, dup_off) = w.shape[1], in_split
+    wp = torch.zeros(w.shape[0], CPAD_IN, 3, 3, dtype=torch.float32, device=w.device)
+    wp[:, :ci], wp[:, lo_off:lo_off + ci], wp[:, dup_off:dup_off + ci] = w_hi, w_hi, w_lo * float(2 ** SPLIT_DUP_LOG2)
+    return wp
+
+
+def split_input_row(x, in_split):
+    """Host twin of ew_nchw_f32_to_nhwc_split_f16 (tests): x fp32 [N, I, H, W] -> fp16 [N, CPAD_IN, H, W] = [x_hi | x_lo | x_hi 2^-10] channel blocks."""
+    lo_off, dup_off = in_split
+    ci = x.shape[1]
+    row = torch.zeros(x.shape[0], CPAD_IN, *x.shape[2:], dtype=torch.float16, device=x.device)
+    hi = x.to(torch.float16)
+    row[:, :ci], row[:, lo_off:lo_off + ci] = hi, (x - hi.float()).to(torch.float16)
+    row[:, dup_off:dup_off + ci] = (hi.float() * 2.0 ** -SPLIT_DUP_LOG2).to(torch.float16)
+    return row
+
+
 def _pad64(c):
     return (c + 63) // 64 * 64
 
@@ -372,10 +399,6 @@ class UNetSpatioTemporalConditionModel:
         def convt(k):              # [O,I,3,1,1] -> [O, K], K = [I/64][3][64]
             return ops.pack_conv_weight(f32(k + ".weight"))
 
-        def hi_lo(w):              # fp32 weight -> (fp16-representable part, remainder), both fp32
-            w_hi = w.to(torch.float16).to(torch.float32)
-            return w_hi, w - w_hi
-
         def lin2(k, c):            # [O, I] -> [O, 2 I] = [W_hi | W_lo] for the level-0 projections (a2 = a), plain fp16 otherwise
             w = f32(k + ".weight")
             if not (self.split_operands and c == self._cfg["block_out_channels"][0]):
@@ -466,11 +489,7 @@ class UNetSpatioTemporalConditionModel:
             if blk.up:
                 W[blk.up.p] = (conv3(blk.up.p), h(f32(blk.up.p + ".bias")))
         if self.in_split:
-            w_hi, w_lo = hi_lo(f32("conv_in.weight"))
-            ci, (lo_off, dup_off) = w_hi.shape[1], self.in_split
-            wp = torch.zeros(w_hi.shape[0], CPAD_IN, 3, 3, dtype=torch.float32, device=dev)
-            wp[:, :ci], wp[:, lo_off:lo_off + ci], wp[:, dup_off:dup_off + ci] = w_hi, w_hi, w_lo * float(2 ** SPLIT_DUP_LOG2)
-            W["conv_in"] = (ops.pack_conv_weight(wp), h(f32("conv_in.bias")))
+            W["conv_in"] = (ops.pack_conv_weight(split_conv_in_weight(f32("conv_in.weight"), self.in_split)), h(f32("conv_in.bias")))
         else:
             W["conv_in"] = (conv3("conv_in", CPAD_IN), h(f32("conv_in.bias")))
         if self.split_operands:     # [W_hi | W_lo] over the input channels: the second block reads the same tensor again (a2 = a)

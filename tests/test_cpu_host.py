@@ -140,3 +140,36 @@ def test_geometry_and_rays_golden(golden_dir):
                                                    [-0.722103, 0, 0.691786, 0.692799]], atol=2e-6)
     np.testing.assert_allclose(equirectangular_to_ray(72, 128).astype(np.float32), g["rays_72x128"], atol=1e-7)
     np.testing.assert_allclose(equirectangular_to_ray(8, 16).astype(np.float32), g["rays_8x16"], atol=1e-7)
+
+
+def test_split_operand_packing_reproduces_fp32_conv():
+    """Round 5 host logic (no GPU): conv_in with both operands split inside its K padding.  The fp16 row [x_hi | x_lo | x_hi 2^-10] against the
+    fp16-rounded pack of [W_hi | W_hi | W_lo 2^10] -- evaluated in fp64 exactly as the MFMA's exact products + fp32-or-better accumulation would --
+    reproduces the fp32 conv to ~1e-6 (x_lo W_lo is the only term left), where single-rounded operands give ~3e-4; and the [W_hi | W_lo] pack of
+    conv_out / the level-0 projections removes the weight term.  Also checks the layout contract ew_nchw_f32_to_nhwc_split_f16 implements."""
+    import torch.nn.functional as F
+    from evoworld_amd.unet import CPAD_IN, SPLIT_DUP_LOG2, hi_lo, split_conv_in_weight, split_in_offsets, split_input_row
+    assert split_in_offsets(18) == (20, 40) and split_in_offsets(21) is None and split_in_offsets(4) == (4, 8)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 18, 12, 20, generator=g)
+    w = (torch.rand(32, 18, 3, 3, generator=g) * 2 - 1) / (18 * 9) ** 0.5
+    sp = split_in_offsets(18)
+    row = split_input_row(x, sp)
+    assert row.shape == (2, CPAD_IN, 12, 20) and row.dtype == torch.float16
+    hi = x.half()
+    assert torch.equal(row[:, :18], hi) and torch.equal(row[:, 20:38], (x - hi.float()).half())
+    assert torch.equal(row[:, 40:58], (hi.float() * 2.0 ** -SPLIT_DUP_LOG2).half())
+    assert (row[:, 18:20] == 0).all() and (row[:, 38:40] == 0).all() and (row[:, 58:] == 0).all()
+    wp = split_conv_in_weight(w, sp).half()                                    # what the loader rounds and packs
+    want = F.conv2d(x.double(), w.double(), padding=1)
+    got = F.conv2d(row.double(), wp.double(), padding=1)
+    single = F.conv2d(hi.double(), w.half().double(), padding=1)
+    e_split = float((got - want).norm() / want.norm())
+    e_single = float((single - want).norm() / want.norm())
+    assert e_split < 3e-6 and e_single > 1e-4, (e_split, e_single)
+    # second K block over the same A: x_hi (W_hi + W_lo) against x_hi W_hi
+    w_hi, w_lo = hi_lo(w)
+    assert torch.equal(w_hi + w_lo, w)
+    two = F.conv2d(torch.cat([hi, hi], 1).double(), torch.cat([w_hi, w_lo], 1).half().double(), padding=1)
+    ref_a = F.conv2d(hi.double(), w.double(), padding=1)                        # activations rounded, weights exact
+    assert float((two - ref_a).norm() / ref_a.norm()) < 3e-6 < float((single - ref_a).norm() / ref_a.norm())
