@@ -191,7 +191,8 @@ def test_unet_full_size_forward_vs_oracle():
     torch.set_num_threads(min(int(__import__("os").environ.get("EW_ORACLE_THREADS", "32")), __import__("os").cpu_count() or 1))
     # EW_FULL_FP32_WEIGHTS=1: the same test under SURVEY §8d's weight protocol (builder-run; result under profiles/)
     fp32w = __import__("os").environ.get("EW_FULL_FP32_WEIGHTS") == "1"
-    m, ref, x, ehs, ids = _setup(cfg, B, T, h, w, seed=7, fp16_representable_weights=not fp32w)
+    seed = int(__import__("os").environ.get("EW_FULL_SEED", "7"))            # (builder-run: a second weight / input seed for the fp32-weights figure)
+    m, ref, x, ehs, ids = _setup(cfg, B, T, h, w, seed=seed, fp16_representable_weights=not fp32w)
     t = torch.tensor(1.6377)
     gt = {}
     got = m(x.cuda(), t, ehs.cuda(), ids.cuda(), return_dict=False, taps=gt)[0]
@@ -210,6 +211,6 @@ def test_unet_full_size_forward_vs_oracle():
         print(f"full-size tap {k:8s} rel-L2 {e:.2e}")
         worst = max(worst, e)
     e = rel_l2(got.cpu(), want)
-    print(f"unet FULL-SIZE forward (B=2, T=25, 72x128 latents, 1.52 B parameters, {'fp32 checkpoint' if fp32w else 'fp16-representable checkpoint'}) rel-L2 {e:.3e}")
+    print(f"unet FULL-SIZE forward (B=2, T=25, 72x128 latents, 1.52 B parameters, seed {seed}, {'fp32 checkpoint' if fp32w else 'fp16-representable checkpoint'}) rel-L2 {e:.3e}")
     assert torch.isfinite(got).all()
     assert worst < (1.8e-3 if fp32w else TOL_TAP) and e < (TOL_FORWARD_FP32_WEIGHTS_FULL if fp32w else TOL_FORWARD)
