@@ -358,7 +358,9 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     dt = time.perf_counter() - t0
+    per_rank_s = D.gather_floats(dt, dev)           # every rank's own clock over the same barrier-bracketed region
     dt = D.max_over_ranks(dt, dev)
+    pg_world, pg_backend = D.world_info()
     unet.forward_nhwc = orig_forward
     finite = all(bool(torch.isfinite(r).all()) for r in res)
     if args.split == "cfg" and world > 1:              # both members of a CFG pair hold the whole clip: they must agree bit for bit
@@ -386,6 +388,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if (args.split == "cfg" and world == 2) else "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            # what torch.distributed itself reports (N > 1: backend "nccl" = RCCL), and each rank's own time per step: a SCALE record can
+            # show that RCCL saw N ranks and how far apart they finished; `value` uses the max
+            "rccl_world": pg_world, "dist_backend": pg_backend, "per_rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank_s],
             "config": {"workload": f"configs[1]: single clip {args.height}x{args.width}x{T}f, {args.denoise_steps} EulerDiscrete "
                                    "steps, CFG batch 2, random-init SVD-Xtend U-Net (in_channels 18), "
                                    + ("one clip per GPU" if args.split == "clip" else

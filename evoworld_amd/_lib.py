@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EW_LIB_PATH") or os.path.join(_HERE, "libevoworld_hip.so")   # EW_LIB_PATH: ablation builds (tools/)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # every symbol declared in include/evoworld_hip.h
 SYMBOLS = [
@@ -24,7 +24,7 @@ SYMBOLS = [
     "ew_u8_hwc_to_f32_chw", "ew_f32_chw_to_u8_hwc", "ew_blur_axis_f32", "ew_bicubic_resize_f32", "ew_vit_patchify_f16",
     "ew_attn_small_f16", "ew_quant_rows_fp8", "ew_gemm_fp8",
     "ew_set_cu_budget", "ew_get_cu_budget", "ew_stream_create_cu_mask", "ew_stream_destroy",
-    "ew_nchw_f32_to_nhwc_split_f16", "ew_euler_cfg_step_split",
+    "ew_nchw_f32_to_nhwc_split_f16", "ew_euler_cfg_step_split", "ew_groupnorm_apply_split_f16", "ew_sinusoid_embed_f16",
 ]
 # entry points newer than ABI 7: an older build of the library loaded for an A/B (EW_LIB_PATH, tools/ab_lib.sh) may lack them
 _NEWER_THAN_ABI7 = {"ew_set_cu_budget", "ew_get_cu_budget", "ew_stream_create_cu_mask", "ew_stream_destroy",      # ABI 8
@@ -89,6 +89,7 @@ def load():
         "ew_groupnorm_stats_f16": [P, P, P, I, I, I, I, I, I, P],
         "ew_groupnorm_finalize": [P, I, I, I, I, P],
         "ew_groupnorm_apply_f16": [P, P, P, P, P, P, I, I, I, I, I, I, F, I, P],
+        "ew_groupnorm_apply_split_f16": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P],
         "ew_gemm_streamk_init": [P],
         "ew_ff_geglu320_f16": [ctypes.POINTER(FfArgs), P],
         "ew_layernorm_f16": [P, P, P, I, P, P, P, P, P, I, I, F, P],
@@ -100,6 +101,7 @@ def load():
         "ew_euler_cfg_step": [P, I, P, P, F, F, P, I, I, I, I, P],
         "ew_nchw_f32_to_nhwc_split_f16": [P, P, I, I, I, I, I, I, I, I, F, P],
         "ew_euler_cfg_step_split": [P, I, P, P, F, F, P, I, I, I, I, I, I, P],
+        "ew_sinusoid_embed_f16": [P, I, I, I, P, P],
         "ew_softmax_rows_f16": [P, P, P, LL, I, LL, P],
         "ew_time_conv3_f32": [P, P, P, P, I, I, I, I, P],
         "ew_plucker_embed": [P, P, P, I, I, I, P],

@@ -30,6 +30,21 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, f16* __restrict
     }
 }
 
+// diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): out[r] = [cos(v f_j) | sin(v f_j)], f_j = exp(-ln(10000) j / half),
+// v = vals[r % n_vals] (one timestep broadcast over the batch rows, or one added-time id per row).  fp32 math in the operation order of the torch
+// expression it replaces (evoworld_amd/unet.py _sinusoid), rounded to fp16 once.
+__global__ void sinusoid_kernel(const float* __restrict__ vals, int n_vals, int n_rows, int dim, f16* __restrict__ out) {
+    const int half = dim / 2;
+    const int total = n_rows * half;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int r = i / half, j = i - r * half;
+        const float f = expf((-9.210340371976184f * (float)j) / (float)half);
+        const float a = vals[r % n_vals] * f;
+        out[(size_t)r * dim + j] = (f16)cosf(a);
+        out[(size_t)r * dim + half + j] = (f16)sinf(a);
+    }
+}
+
 __global__ void nhwc_to_nchw_kernel(const f16* __restrict__ x, float* __restrict__ y, int N, int C, int HW, int ldc) {
     const long long total = (long long)N * HW;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -186,6 +201,13 @@ extern "C" ew_status ew_nchw_f32_to_nhwc_split_f16(const float* x, void* y, int 
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long long)N * H * W)), dim3(256), 0, (hipStream_t)stream, x,
                        (f16*)y, N, C, H * W, ldc, c_off, scale, lo_off, dup_off);
     return ew_check_launch("ew_nchw_f32_to_nhwc_split_f16");
+}
+
+extern "C" ew_status ew_sinusoid_embed_f16(const float* vals, int n_vals, int n_rows, int dim, void* out, void* stream) {
+    EW_REQUIRE(vals && out && n_vals > 0 && n_rows > 0 && dim > 0 && dim % 2 == 0, "ew_sinusoid_embed_f16: bad args");
+    const int total = n_rows * (dim / 2);
+    hipLaunchKernelGGL(sinusoid_kernel, dim3(ew_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, vals, n_vals, n_rows, dim, (f16*)out);
+    return ew_check_launch("ew_sinusoid_embed_f16");
 }
 
 extern "C" ew_status ew_nhwc_f16_to_nchw_f32(const void* x, float* y, int N, int C, int H, int W, int ldc, void* stream) {

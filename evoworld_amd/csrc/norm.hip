@@ -188,9 +188,12 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 // threads, every thread owns one fixed 8-channel vector of one slab -> mean / rstd / gamma / beta collapse ONCE per thread
 // into scale[8], shift[8]; the row loop is load, 8 fma (+SiLU), store.  (The first version re-derived (row, column, slab,
 // group) with 64-bit divisions for every vector and ran at 2.8 TB/s.)
-template <bool LO>
+// YLO: the result is written as a SPLIT OPERAND (round 6): y = fp16(f) and y_lo = fp16(f - float(y)) with the same row stride ld_y -- the
+// [x_hi | x_lo] A operand of a consumer whose weights are packed [W_hi | W_hi | W_lo] (conv_out, the level-0 proj_in).
+template <bool LO, bool YLO>
 __global__ void gn_apply_kernel(const f16* __restrict__ x, const int8_t* __restrict__ x_lo, const float* __restrict__ stats,
-                                const f16* __restrict__ gamma, const f16* __restrict__ beta, f16* __restrict__ y, int rows,
+                                const f16* __restrict__ gamma, const f16* __restrict__ beta, f16* __restrict__ y,
+                                f16* __restrict__ y_lo, int ld_y, int rows,
                                 int C_src, int c_off, int C_tot, int groups, float eps, int silu, int VPP, int PL,
                                 int rows_per_block) {
     const int tid = threadIdx.x;
@@ -220,7 +223,8 @@ __global__ void gn_apply_kernel(const f16* __restrict__ x, const int8_t* __restr
     const int r1 = min(rows, r0 + rows_per_block);
     const f16* xin = x + ((size_t)slab * rows) * C_src + c;
     const int8_t* xlo = LO ? x_lo + ((size_t)slab * rows) * C_src + c : nullptr;
-    f16* yout = y + ((size_t)slab * rows) * C_tot + c_off + c;
+    f16* yout = y + ((size_t)slab * rows) * ld_y + c_off + c;
+    f16* ylo = YLO ? y_lo + ((size_t)slab * rows) * ld_y + c_off + c : nullptr;
     int r = r0 + pl;
     for (; r + 3 * PL < r1; r += 4 * PL) {
         f16x8 val[4];
@@ -232,7 +236,7 @@ __global__ void gn_apply_kernel(const f16* __restrict__ x, const int8_t* __restr
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            f16x8 o;
+            f16x8 o, ol;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float xv;
@@ -241,15 +245,17 @@ __global__ void gn_apply_kernel(const f16* __restrict__ x, const int8_t* __restr
                 float f = (xv - shift[e]) * scale[e] * (float)gm[e] + (float)bt[e];
                 if (silu) f = ew_silu(f);
                 o[e] = (f16)f;
+                if constexpr (YLO) ol[e] = (f16)(f - (float)o[e]);
             }
-            *(f16x8*)(yout + (size_t)(r + u * PL) * C_tot) = o;
+            *(f16x8*)(yout + (size_t)(r + u * PL) * ld_y) = o;
+            if constexpr (YLO) *(f16x8*)(ylo + (size_t)(r + u * PL) * ld_y) = ol;
         }
     }
     for (; r < r1; r += PL) {
         const f16x8 val = *(const f16x8*)(xin + (size_t)r * C_src);
         u32x2 vlo;
         if constexpr (LO) vlo = *(const u32x2*)(xlo + (size_t)r * C_src);
-        f16x8 o;
+        f16x8 o, ol;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float xv;
@@ -258,8 +264,10 @@ __global__ void gn_apply_kernel(const f16* __restrict__ x, const int8_t* __restr
             float f = (xv - shift[e]) * scale[e] * (float)gm[e] + (float)bt[e];
             if (silu) f = ew_silu(f);
             o[e] = (f16)f;
+            if constexpr (YLO) ol[e] = (f16)(f - (float)o[e]);
         }
-        *(f16x8*)(yout + (size_t)r * C_tot) = o;
+        *(f16x8*)(yout + (size_t)r * ld_y) = o;
+        if constexpr (YLO) *(f16x8*)(ylo + (size_t)r * ld_y) = ol;
     }
 }
 
@@ -414,27 +422,43 @@ extern "C" ew_status ew_groupnorm_finalize(float* ws, int n_slabs, int rows, int
     return ew_check_launch("ew_groupnorm_finalize");
 }
 
+static ew_status gn_apply_launch(const char* what, const void* x, const void* x_lo, const float* ws, const void* gamma,
+                                 const void* beta, void* y, void* y_lo, int ld_y, int n_slabs, int rows, int C_src, int c_off,
+                                 int C_tot, int groups, float eps, int silu, void* stream) {
+    EW_REQUIRE(x && ws && gamma && beta && y, "ew_groupnorm_apply: null pointer");
+    EW_REQUIRE(n_slabs > 0 && rows > 0 && C_src > 0 && C_src % 8 == 0 && c_off % 8 == 0 && C_tot % 8 == 0,
+               "ew_groupnorm_apply: bad shape");
+    EW_REQUIRE(groups > 0 && C_tot % groups == 0 && c_off >= 0 && c_off + C_src <= C_tot, "ew_groupnorm_apply: bad groups");
+    EW_REQUIRE(ld_y >= C_tot && ld_y % 8 == 0, "ew_groupnorm_apply: bad output row stride");
+    const int VPP = C_src / 8;
+    EW_REQUIRE(VPP <= 1024, "ew_groupnorm_apply: C_src too large");
+    const int PL = VPP >= 256 ? 1 : 256 / VPP;
+    const int rpb = 8 * PL;                                    // rows per block: 8 per thread column (round 4: 32 -> 8, level-0 apply 139 -> 127 us: smaller blocks, better balance)
+    const GnWs w = gn_ws((float*)ws, n_slabs, rows, C_tot);
+    dim3 grid(ew_cdiv(rows, rpb), n_slabs);
+#define GN_APPLY(LO_, YLO_)                                                                                                      \
+    hipLaunchKernelGGL((gn_apply_kernel<LO_, YLO_>), grid, dim3(VPP * PL), 0, (hipStream_t)stream, (const f16*)x,                  \
+                       (const int8_t*)x_lo, w.stats, (const f16*)gamma, (const f16*)beta, (f16*)y, (f16*)y_lo, ld_y, rows, C_src,  \
+                       c_off, C_tot, groups, eps, silu, VPP, PL, rpb)
+    if (x_lo) { if (y_lo) GN_APPLY(true, true); else GN_APPLY(true, false); }
+    else      { if (y_lo) GN_APPLY(false, true); else GN_APPLY(false, false); }
+#undef GN_APPLY
+    return ew_check_launch(what);
+}
+
 extern "C" ew_status ew_groupnorm_apply_f16(const void* x, const void* x_lo, const float* ws, const void* gamma,
                                             const void* beta, void* y, int n_slabs, int rows, int C_src, int c_off, int C_tot,
                                             int groups, float eps, int silu, void* stream) {
-    EW_REQUIRE(x && ws && gamma && beta && y, "ew_groupnorm_apply_f16: null pointer");
-    EW_REQUIRE(n_slabs > 0 && rows > 0 && C_src > 0 && C_src % 8 == 0 && c_off % 8 == 0 && C_tot % 8 == 0,
-               "ew_groupnorm_apply_f16: bad shape");
-    EW_REQUIRE(groups > 0 && C_tot % groups == 0 && c_off >= 0 && c_off + C_src <= C_tot, "ew_groupnorm_apply_f16: bad groups");
-    const int VPP = C_src / 8;
-    EW_REQUIRE(VPP <= 1024, "ew_groupnorm_apply_f16: C_src too large");
-    const int PL = VPP >= 256 ? 1 : 256 / VPP;
-    static const int apply_rows = getenv("EW_GN_APPLY_ROWS") ? atoi(getenv("EW_GN_APPLY_ROWS")) : 8;    // A/B hook
-    const int rpb = apply_rows * PL;                           // rows per block: 8 per thread column (round 4: 32 -> 8, level-0 apply 139 -> 127 us: smaller blocks, better balance)
-    const GnWs w = gn_ws((float*)ws, n_slabs, rows, C_tot);
-    dim3 grid(ew_cdiv(rows, rpb), n_slabs);
-    if (x_lo)
-        hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(VPP * PL), 0, (hipStream_t)stream, (const f16*)x, (const int8_t*)x_lo,
-                           w.stats, (const f16*)gamma, (const f16*)beta, (f16*)y, rows, C_src, c_off, C_tot, groups, eps, silu, VPP, PL, rpb);
-    else
-        hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(VPP * PL), 0, (hipStream_t)stream, (const f16*)x, (const int8_t*)nullptr,
-                           w.stats, (const f16*)gamma, (const f16*)beta, (f16*)y, rows, C_src, c_off, C_tot, groups, eps, silu, VPP, PL, rpb);
-    return ew_check_launch("ew_groupnorm_apply_f16");
+    return gn_apply_launch("ew_groupnorm_apply_f16", x, x_lo, ws, gamma, beta, y, nullptr, C_tot, n_slabs, rows, C_src, c_off, C_tot,
+                           groups, eps, silu, stream);
+}
+
+extern "C" ew_status ew_groupnorm_apply_split_f16(const void* x, const void* x_lo, const float* ws, const void* gamma,
+                                                  const void* beta, void* y, void* y_lo, int ld_y, int n_slabs, int rows, int C_src,
+                                                  int c_off, int C_tot, int groups, float eps, int silu, void* stream) {
+    EW_REQUIRE(y_lo, "ew_groupnorm_apply_split_f16: null pointer");
+    return gn_apply_launch("ew_groupnorm_apply_split_f16", x, x_lo, ws, gamma, beta, y, y_lo, ld_y, n_slabs, rows, C_src, c_off, C_tot,
+                           groups, eps, silu, stream);
 }
 
 extern "C" ew_status ew_layernorm_f16(const void* x, const void* x_lo, const void* addvec, int rows_per_group, void* x_out,

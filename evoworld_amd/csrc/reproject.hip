@@ -214,16 +214,14 @@ __global__ __launch_bounds__(256) void compact_scatter_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------
 // splat: 4 points per thread (three 16-byte loads), all views x faces per point; matrices are wave-uniform (SGPRs)
 // ------------------------------------------------------------------------------------------------
-// VIEW_MAJOR = 0: every point is read once and walks all V*6 matrices.  VIEW_MAJOR = 1: blockIdx.y = view; the cloud is
-// re-read per view (coalesced, it stays in the Infinity Cache) but all resident waves hit the SAME view's 6 z-buffers
-// (12.6 MB at 512^2) instead of all V of them (302 MB): the fragment traffic is random 8-byte cells, so its footprint decides
-// whether it is served by L2 / Infinity Cache or by HBM.
-template <int VIEW_MAJOR>
+// Every point is read once and walks all V*6 matrices (point-major).  A view-major variant (blockIdx.y = view, the cloud re-read per view so that
+// all resident waves hit ONE view's 12.6 MB of z-buffers instead of all 302 MB) measured 2.83 vs 2.64 ms at 5 M points x 24 views: the kernel is
+// bound by the rate of memory-side 8-byte transactions (~45 G fragments/s), not by the footprint -- removed in round 6.
 __global__ __launch_bounds__(256) void splat_kernel(const float* __restrict__ xyz, unsigned npts, const float* __restrict__ w2c,
                                                     u64* __restrict__ zbuf, int V, int res, float fx, float fy, float cx,
                                                     float cy, float z_near) {
     const float fres = (float)res;
-    const int vf0 = VIEW_MAJOR ? blockIdx.y * 6 : 0, vf1 = VIEW_MAJOR ? vf0 + 6 : V * 6;
+    const int vf0 = 0, vf1 = V * 6;
     for (size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; base < npts; base += (size_t)gridDim.x * 1024) {
         float px[4], py[4], pz[4];
         const int cnt = (int)min((size_t)4, (size_t)npts - base);
@@ -268,6 +266,14 @@ __global__ __launch_bounds__(256) void splat_kernel(const float* __restrict__ xy
             }
         }
     }
+}
+
+// z-buffer init: every cell = 0xFFFF...F ("no fragment"), 16-byte stores
+__global__ __launch_bounds__(256) void zfill_kernel(u64* __restrict__ zbuf, size_t ncell) {
+    const u32x4 ones = {~0u, ~0u, ~0u, ~0u};
+    const size_t n2 = ncell / 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) *(u32x4*)(zbuf + i * 2) = ones;
+    if ((ncell & 1) && blockIdx.x == 0 && threadIdx.x == 0) zbuf[ncell - 1] = ~0ull;
 }
 
 // z-buffer -> colours.  CI: colour stride in bytes per point (3: packed RGB, 4: RGBX words); CO: output channels (3 | 4)
@@ -569,23 +575,15 @@ extern "C" ew_status ew_splat_cubemap(const float* xyz, size_t npts, const float
                                       int res, float fx, float fy, float cx, float cy, float z_near, void* stream) {
     EW_REQUIRE(w2c && zbuf && V > 0 && res > 0, "ew_splat_cubemap: bad args");
     EW_REQUIRE(npts < 0xffffffffULL, "ew_splat_cubemap: npts must fit 32 bits");
-    if (npts == 0) return EW_OK;   // empty cloud: z-buffers stay at their init value
+    EW_REQUIRE(((uintptr_t)zbuf & 15) == 0, "ew_splat_cubemap: zbuf must be 16-byte aligned");
+    // round 6: the z-buffers are initialised HERE (they were the caller's job -- a torch fill kernel on the product path -- until ABI 9)
+    const size_t ncell = (size_t)V * 6 * res * res;
+    hipLaunchKernelGGL(zfill_kernel, dim3(grid_for((long long)(ncell / 2 + 1), 256)), dim3(256), 0, (hipStream_t)stream, zbuf, ncell);
+    if (npts == 0) return ew_check_launch("ew_splat_cubemap");   // empty cloud: every cell stays "no fragment"
     EW_REQUIRE(xyz && ((uintptr_t)xyz & 15) == 0, "ew_splat_cubemap: xyz must be non-null and 16-byte aligned");
-    const char* mode = getenv("EW_SPLAT_MODE");
-    // default: point-major (every point read once).  Measured on MI355X at 5 M points x 24 views (bench_reproject.py):
-    // point-major 2.64 ms, view-major 2.83 ms -- the z-buffer footprint (302 MB vs 12.6 MB) does not matter, the kernel is
-    // bound by the rate of memory-side 8-byte transactions (119 M fragments: ~45 G fragments/s), not by bytes.
-    const bool view_major = mode && mode[0] == 'v';
     int grid = grid_for((long long)(npts + 3) / 4, 256);
-    if (view_major) {
-        if (grid > 512) grid = 512;
-        hipLaunchKernelGGL(splat_kernel<1>, dim3(grid, V), dim3(256), 0, (hipStream_t)stream, xyz, (unsigned)npts, w2c, zbuf, V,
-                           res, fx, fy, cx, cy, z_near);
-    } else {
-        if (grid > 1024) grid = 1024;
-        hipLaunchKernelGGL(splat_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, xyz, (unsigned)npts, w2c, zbuf, V,
-                           res, fx, fy, cx, cy, z_near);
-    }
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(splat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, xyz, (unsigned)npts, w2c, zbuf, V, res, fx, fy, cx, cy, z_near);
     return ew_check_launch("ew_splat_cubemap");
 }
 

@@ -74,7 +74,10 @@ def load_single_segment_batch(episode_path, height=576, width=1024, device="cuda
         names = sorted(f for f in os.listdir(rdir) if f.endswith(".png"))
         renders = [_open_rgb(os.path.join(rdir, f"{i:02}.png")) for i in range(len(names))]      # :478-505
         first = _to_pixel_values([_open_rgb(os.path.join(episode_path, "panorama", "001.png"))], height, width, device)
-        mem = torch.cat([first, _to_pixel_values(renders, height, width, device)], dim=0)        # first frame inserted at 0 (:506-514)
+        # first frame inserted at 0 (:506-514).  With sequence_length < 25 (BASELINE configs[0]: 8 frames) the reference's dataset still returns all
+        # 1 + 24 memory frames and its pipeline then fails the channel concat at pipeline_evoworld.py:643; here the memory is cut to the window
+        # length ([001] + renders 00 .. sequence_length - 2), which for the default 25 is the identity
+        mem = torch.cat([first, _to_pixel_values(renders[:sequence_length - 1], height, width, device)], dim=0)
     return {"pixel_values": pix[None], "cam_traj": traj[None], "memorized_pixel_values": mem[None],
             "memorized_cam_traj": traj[None].clone(), "episode_path": [episode_path]}
 

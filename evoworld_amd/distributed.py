@@ -73,6 +73,24 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
+def gather_floats(value, device):
+    """all_gather of one float per rank -> list in rank order (bench.py: per-rank seconds next to the max the metric is computed from)."""
+    if _single():
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def world_info():
+    """(process-group world size, backend name) as torch.distributed reports them -- (1, None) without a process group.  A multi-GPU bench
+    line carries these so that a scaling record can show RCCL ("nccl") really saw N ranks."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), str(dist.get_backend())
+    return 1, None
+
+
 def shutdown():
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()

@@ -184,9 +184,10 @@ class WorkspacePool:
 SumsPool = WorkspacePool   # former name
 
 
-def groupnorm(xs, gamma, beta, n_slabs, rows, eps, silu, groups=32, out=None, pool=None, stats_hi_only=False):
+def groupnorm(xs, gamma, beta, n_slabs, rows, eps, silu, groups=32, out=None, pool=None, stats_hi_only=False, split_out=False):
     """GroupNorm(+SiLU) over the channel concat of `xs` (list of [n_slabs*rows, C_i] fp16 tensors or `Res`) ->
-    [n_slabs*rows, sum C_i] fp16.  Deterministic shifted statistics: stats per source, one finalize, apply per source."""
+    [n_slabs*rows, sum C_i] fp16.  Deterministic shifted statistics: stats per source, one finalize, apply per source.
+    split_out: the result is the split operand [n_slabs*rows, 2 * sum C_i] = [y_hi | y_lo], y_lo = fp16(y - y_hi) (ew_groupnorm_apply_split_f16)."""
     lib = _lib.load()
     srcs = [_hl(x) for x in xs]
     C_tot = sum(h.shape[-1] for h, _ in srcs)
@@ -194,7 +195,7 @@ def groupnorm(xs, gamma, beta, n_slabs, rows, eps, silu, groups=32, out=None, po
     nws = lib.ew_groupnorm_workspace_floats(n_slabs, rows, C_tot, groups)
     ws = pool.take(nws) if pool is not None else torch.empty(nws, dtype=torch.float32, device=dev)
     if out is None:
-        out = torch.empty(n_slabs * rows, C_tot, dtype=torch.float16, device=dev)
+        out = torch.empty(n_slabs * rows, 2 * C_tot if split_out else C_tot, dtype=torch.float16, device=dev)
     st = _stream()
     off = 0
     for h, l in srcs:
@@ -207,9 +208,14 @@ def groupnorm(xs, gamma, beta, n_slabs, rows, eps, silu, groups=32, out=None, po
     _lib.check(lib.ew_groupnorm_finalize(_ptr(ws), n_slabs, rows, C_tot, groups, st), "ew_groupnorm_finalize")
     off = 0
     for h, l in srcs:
-        _lib.check(lib.ew_groupnorm_apply_f16(_ptr(h), _ptr(l), _ptr(ws), _ptr(gamma), _ptr(beta), _ptr(out), n_slabs, rows,
-                                              h.shape[-1], off, C_tot, groups, eps, 1 if silu else 0, st),
-                   "ew_groupnorm_apply_f16")
+        if split_out:
+            _lib.check(lib.ew_groupnorm_apply_split_f16(_ptr(h), _ptr(l), _ptr(ws), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(out[:, C_tot:]),
+                                                        2 * C_tot, n_slabs, rows, h.shape[-1], off, C_tot, groups, eps, 1 if silu else 0, st),
+                       "ew_groupnorm_apply_split_f16")
+        else:
+            _lib.check(lib.ew_groupnorm_apply_f16(_ptr(h), _ptr(l), _ptr(ws), _ptr(gamma), _ptr(beta), _ptr(out), n_slabs, rows,
+                                                  h.shape[-1], off, C_tot, groups, eps, 1 if silu else 0, st),
+                       "ew_groupnorm_apply_f16")
         off += h.shape[-1]
     return out
 
@@ -271,6 +277,15 @@ def time_conv3(x, w, bias):
     y = torch.empty_like(x)
     _lib.check(lib.ew_time_conv3_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, T, C, H * W, _stream()), "ew_time_conv3_f32")
     return y
+
+
+def sinusoid_embed(vals, n_rows, dim):
+    """vals fp32 device [n] -> fp16 [n_rows, dim] = [cos | sin] sinusoidal embedding of vals[row % n] (ew_sinusoid_embed_f16)."""
+    lib = _lib.load()
+    _req(vals, torch.float32, "vals")
+    out = torch.empty(n_rows, dim, dtype=torch.float16, device=vals.device)
+    _lib.check(lib.ew_sinusoid_embed_f16(_ptr(vals), vals.numel(), n_rows, dim, _ptr(out), _stream()), "ew_sinusoid_embed_f16")
+    return out
 
 
 def nchw_f32_to_nhwc_f16(x, y, ldc, c_off=0, scale=1.0, split=None):
@@ -380,7 +395,7 @@ def splat_cubemap(xyz, rgb, w2c, res, fx, fy, cx, cy, z_near, face_channels=3):
     else:
         rgb, stride = rgb.contiguous(), 3
     V = w2c.shape[0]
-    zbuf = torch.full((V, 6, res, res), -1, dtype=torch.int64, device=xyz.device)  # 0xFFFF... as u64
+    zbuf = torch.empty((V, 6, res, res), dtype=torch.int64, device=xyz.device)     # initialised by ew_splat_cubemap itself (0xFFFF... = no fragment)
     _lib.check(lib.ew_splat_cubemap(_ptr(xyz), xyz.shape[0], _ptr(w2c), _ptr(zbuf), V, res, fx, fy, cx, cy, z_near,
                                     _stream()), "ew_splat_cubemap")
     faces = torch.empty(V, 6, res, res, face_channels, dtype=torch.uint8, device=xyz.device)

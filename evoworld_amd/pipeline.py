@@ -221,8 +221,8 @@ class StableVideoDiffusionPipeline:
         for half in range(2):  # latents duplicated on both CFG rows, scale_model_input for step 0 (:691-692)
             ops.nchw_f32_to_nhwc_f16(lat, x_in[half * T * h * w:], CPAD_IN, c_off=0, scale=1.0 / (s0 * s0 + 1.0) ** 0.5, split=split)
         guidance = guidance.to(device=dev, dtype=torch.float32).contiguous()
-        ehs = image_embeddings.to(dev)
-        ids = added_time_ids.to(dev)
+        ehs = image_embeddings.to(device=dev, dtype=torch.float16)        # once per clip: the forward takes fp16 embeddings / fp32 ids as they are
+        ids = added_time_ids.to(device=dev, dtype=torch.float32)
         grp = cfg_group if cfg_group is not None else self.cfg_group
         if grp is None:
             for i in range(num_inference_steps):

@@ -232,14 +232,6 @@ def random_state_dict(cfg, seed=0, device="cpu"):
     return sd
 
 
-def _sinusoid(x, dim):
-    """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]."""
-    half = dim // 2
-    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=x.device) / half)
-    args = x.reshape(-1, 1).float() * freqs[None]
-    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
-
-
 class UNetSpatioTemporalConditionModel:
     def __init__(self, **config):
         cfg = dict(DEFAULT_CONFIG)
@@ -280,8 +272,14 @@ class UNetSpatioTemporalConditionModel:
         #     [W_hi | W_hi | W_lo 2^10]: zero extra MFMA work;
         #   * conv_out and the proj_in / proj_out GEMMs of the 320-channel transformers: W = W_hi + W_lo as a second K block over the SAME A
         #     operand (the dual-source addressing mode of the skip concat: a2 = a), K doubles on ~14 small launches.
-        # EW_SPLIT_OPERANDS=0 restores single-rounded operands everywhere (A/B).
-        self.split_operands = os.environ.get("EW_SPLIT_OPERANDS", "1") != "0"
+        # Round 6: the ACTIVATION side of conv_out and of the level-0 proj_in as well -- their A operand is a GroupNorm output, which
+        # ew_groupnorm_apply_split_f16 writes as the row [y_hi | y_lo]; the weights become three K blocks [W_hi | W_hi | W_lo] (source 2 = the
+        # y_hi half again), i.e. x W to ~2^-21 in both operands: -16 % of the activation-rounding term (per-group shares: conv_out 7.8 %,
+        # level-0 proj_in ~8 %) for one more 320-wide K block on 6 small launches.
+        # EW_SPLIT_OPERANDS=0 restores single-rounded operands everywhere, =1 the round-5 set (weights only outside conv_in) (A/B).
+        so = int(os.environ.get("EW_SPLIT_OPERANDS", "2"))
+        self.split_operands = so != 0
+        self.split_acts = so >= 2
         self.in_split = split_in_offsets(cfg["in_channels"]) if self.split_operands else None
         self._pos_cache = {}
         for hd, c in zip(cfg["num_attention_heads"], cfg["block_out_channels"]):
@@ -399,11 +397,12 @@ class UNetSpatioTemporalConditionModel:
         def convt(k):              # [O,I,3,1,1] -> [O, K], K = [I/64][3][64]
             return ops.pack_conv_weight(f32(k + ".weight"))
 
-        def lin2(k, c):            # [O, I] -> [O, 2 I] = [W_hi | W_lo] for the level-0 projections (a2 = a), plain fp16 otherwise
-            w = f32(k + ".weight")
+        def lin2(k, c, acts=False):  # [O, I] -> [O, 2 I] = [W_hi | W_lo] for the level-0 projections (a2 = a), plain fp16 otherwise;
+            w = f32(k + ".weight")    # acts: [O, 3 I] = [W_hi | W_hi | W_lo] against the split A operand [x_hi | x_lo] + x_hi again
             if not (self.split_operands and c == self._cfg["block_out_channels"][0]):
                 return h(w)
-            return h(torch.cat(hi_lo(w), dim=1))
+            w_hi, w_lo = hi_lo(w)
+            return h(torch.cat([w_hi, w_hi, w_lo] if acts else [w_hi, w_lo], dim=1))
 
         def geglu(k):              # interleave value/gate rows in blocks of 16 (see ew_gemm_f16)
             w, b = f32(k + ".weight"), f32(k + ".bias")
@@ -443,7 +442,7 @@ class UNetSpatioTemporalConditionModel:
             d = {}
             c = t.ch
             d["ng"], d["nb"] = h(f32(t.p + ".norm.weight")), h(f32(t.p + ".norm.bias"))
-            d["piw"], d["pib"] = lin2(t.p + ".proj_in", c), h(f32(t.p + ".proj_in.bias"))
+            d["piw"], d["pib"] = lin2(t.p + ".proj_in", c, self.split_acts), h(f32(t.p + ".proj_in.bias"))
             d["pow"], d["pob"] = lin2(t.p + ".proj_out", c), h(f32(t.p + ".proj_out.bias"))
             d["mix"] = float(torch.sigmoid(f32(t.p + ".time_mixer.mix_factor")).item())
             d["pe1w"], d["pe1b"] = h(f32(t.p + ".time_pos_embed.linear_1.weight")), h(f32(t.p + ".time_pos_embed.linear_1.bias"))
@@ -492,8 +491,9 @@ class UNetSpatioTemporalConditionModel:
             W["conv_in"] = (ops.pack_conv_weight(split_conv_in_weight(f32("conv_in.weight"), self.in_split)), h(f32("conv_in.bias")))
         else:
             W["conv_in"] = (conv3("conv_in", CPAD_IN), h(f32("conv_in.bias")))
-        if self.split_operands:     # [W_hi | W_lo] over the input channels: the second block reads the same tensor again (a2 = a)
-            W["conv_out"] = (ops.pack_conv_weight(torch.cat(hi_lo(f32("conv_out.weight")), dim=1)), h(f32("conv_out.bias")))
+        if self.split_operands:     # [W_hi | W_lo] over the input channels: the second block reads the same tensor again (a2 = a);
+            w_hi, w_lo = hi_lo(f32("conv_out.weight"))      # split_acts: [W_hi | W_hi | W_lo] against the [x_hi | x_lo] rows of conv_norm_out
+            W["conv_out"] = (ops.pack_conv_weight(torch.cat([w_hi, w_hi, w_lo] if self.split_acts else [w_hi, w_lo], dim=1)), h(f32("conv_out.bias")))
         else:
             W["conv_out"] = (conv3("conv_out"), h(f32("conv_out.bias")))
         W["no_g"], W["no_b"] = h(f32("conv_norm_out.weight")), h(f32("conv_norm_out.bias"))
@@ -508,12 +508,14 @@ class UNetSpatioTemporalConditionModel:
     def _res(self, rows, C, dev, head=False):
         return Res.empty(rows, C, dev, self.split_heads if head else self.split_residual)
 
-    def _conv3x3(self, x, x2, w, b, N, H, W_, Ho, Wo, stride=1, upsample=0, res_out=False, **kw):
+    def _conv3x3(self, x, x2, w, b, N, H, W_, Ho, Wo, stride=1, upsample=0, res_out=False, c2=None, **kw):
+        """c2: channels of the second source when they are fewer than its row width (x2 = the [x_hi | x_lo] rows read again for x_hi)."""
         c1 = x.shape[-1]
-        c2 = x2.shape[-1] if x2 is not None else 0
+        lda2 = x2.shape[-1] if x2 is not None else 0
+        c2 = lda2 if c2 is None else c2
         M = N * Ho * Wo
         out = self._res(M, w.shape[0], x.device, head="r1" not in kw) if res_out else torch.empty(M, w.shape[0], dtype=torch.float16, device=x.device)
-        return ops.gemm(x, w, out, M=M, N=w.shape[0], c1=c1, lda=c1, a2=x2, c2=c2, lda2=c2, bias=b,
+        return ops.gemm(x, w, out, M=M, N=w.shape[0], c1=c1, lda=c1, a2=x2, c2=c2, lda2=lda2, bias=b,
                         mode=A_CONV3X3, conv=(N, H, W_, Ho, Wo, stride, upsample), **kw)
 
     def _convt(self, x, w, b, B, T, P, res_out=False, **kw):
@@ -523,11 +525,13 @@ class UNetSpatioTemporalConditionModel:
         return ops.gemm(x, w, out, M=M, N=w.shape[0], c1=C, lda=C, bias=b, mode=A_CONVT3, tconv=(B, T, P), **kw)
 
     def _lin2(self, x, w, b, out, **kw):
-        """Linear whose weight may be packed [W_hi | W_lo] (twice the input width): the second K block reads x again (a2 = a)."""
+        """Linear whose weight may be packed [W_hi | W_lo] (twice the input width): the second K block reads x again (a2 = a); or
+        [W_hi | W_hi | W_lo] against split rows x = [x_hi | x_lo] (1.5 x the row width): the third block reads the x_hi half again."""
         C = x.shape[-1]
         if w.shape[1] == C:
             return ops.linear(x, w, b, out=out, **kw)
-        return ops.gemm(x, w, out, M=x.shape[0], N=w.shape[0], c1=C, lda=C, a2=x, c2=C, lda2=C, bias=b, **kw)
+        c2 = w.shape[1] - C         # = C (plain rows) or C / 2 (split rows)
+        return ops.gemm(x, w, out, M=x.shape[0], N=w.shape[0], c1=C, lda=C, a2=x, c2=c2, lda2=C, bias=b, **kw)
 
     def _resblock(self, r, xs, tembs, B, T, H, W_):
         """SpatioTemporalResBlock = ResnetBlock2D -> TemporalResnetBlock -> AlphaBlender.
@@ -567,7 +571,7 @@ class UNetSpatioTemporalConditionModel:
         key = (t.p, B, T)
         if key not in self._pos_cache:
             d = self.w[t.p]
-            sin = _sinusoid(torch.arange(T, device=self.device), t.ch).to(torch.float16).contiguous()
+            sin = ops.sinusoid_embed(torch.arange(T, device=self.device, dtype=torch.float32), T, t.ch)
             e = ops.linear(ops.linear(sin, d["pe1w"], d["pe1b"], act=ACT_SILU), d["pe2w"], d["pe2b"])
             self._pos_cache[key] = e.repeat(B, 1).contiguous()
         return self._pos_cache[key]
@@ -582,7 +586,7 @@ class UNetSpatioTemporalConditionModel:
         dev = x.hi.device
         cv_s = cvecs[:, self._cv_off[(t.p, "s")]:]
         cv_t = cvecs[:, self._cv_off[(t.p, "t")]:]
-        hn = ops.groupnorm([x], d["ng"], d["nb"], N, S, 1e-6, False, pool=self._gn_pool)
+        hn = ops.groupnorm([x], d["ng"], d["nb"], N, S, 1e-6, False, pool=self._gn_pool, split_out=d["piw"].shape[1] == 3 * C)
         h = self._lin2(hn, d["piw"], d["pib"], self._res(rows, C, dev, head=True))
         # --- spatial BasicTransformerBlock ---
         n1 = ops.layernorm(h, d["s_norm1g"], d["s_norm1b"])
@@ -671,10 +675,11 @@ class UNetSpatioTemporalConditionModel:
         self._gn_pool.reset()
         boc = cfg["block_out_channels"]
         N = B * T
-        ts = torch.as_tensor(timestep, dtype=torch.float32, device=dev).reshape(-1).expand(B)
-        t_emb = _sinusoid(ts, boc[0]).to(torch.float16).contiguous()
-        a_emb = _sinusoid(added_time_ids.to(dev).flatten(), cfg["addition_time_embed_dim"]).reshape(B, -1)
-        a_emb = a_emb.to(torch.float16).contiguous()
+        # timestep / added-time-id embeddings: one ew_sinusoid_embed_f16 launch each (diffusers Timesteps; no torch elementwise kernels in a forward)
+        ts = torch.as_tensor(timestep, dtype=torch.float32, device=dev).reshape(-1)
+        t_emb = ops.sinusoid_embed(ts, B, boc[0])                          # one timestep broadcast over the batch rows, or one per row
+        ids = added_time_ids if (added_time_ids.device == dev and added_time_ids.dtype == torch.float32) else added_time_ids.to(device=dev, dtype=torch.float32)
+        a_emb = ops.sinusoid_embed(ids.reshape(-1).contiguous(), B * ids.shape[-1], cfg["addition_time_embed_dim"]).reshape(B, -1)
         h1 = ops.linear(t_emb, Wt["te1w"], Wt["te1b"], act=ACT_SILU)
         h2 = ops.linear(a_emb, Wt["ae1w"], Wt["ae1b"], act=ACT_SILU)
         td = boc[0] * 4
@@ -720,9 +725,11 @@ class UNetSpatioTemporalConditionModel:
                 H, W_ = 2 * H, 2 * W_
             if taps is not None:
                 taps[f"up{bi}"] = (h.float(), H, W_)
-        hn = ops.groupnorm([h], Wt["no_g"], Wt["no_b"], N, H * W_, 1e-5, True, pool=self._gn_pool)
-        wco, bco = Wt["conv_out"]       # packed [W_hi | W_lo] (twice the input channels): the second block reads hn again
-        return self._conv3x3(hn, hn if wco.shape[1] == 2 * 9 * hn.shape[-1] else None, wco, bco, N, H, W_, H, W_)
+        wco, bco = Wt["conv_out"]       # packed [W_hi | W_lo] (twice the input channels): the second block reads hn again;
+        C0 = h.hi.shape[-1]             # or [W_hi | W_hi | W_lo] against the split rows [hn_hi | hn_lo] + hn_hi again
+        blocks = wco.shape[1] // (9 * C0)
+        hn = ops.groupnorm([h], Wt["no_g"], Wt["no_b"], N, H * W_, 1e-5, True, pool=self._gn_pool, split_out=blocks == 3)
+        return self._conv3x3(hn, hn if blocks > 1 else None, wco, bco, N, H, W_, H, W_, c2=C0 if blocks > 1 else None)
 
     @torch.no_grad()
     def __call__(self, sample, timestep, encoder_hidden_states, added_time_ids, return_dict=True, taps=None):

@@ -27,7 +27,7 @@ typedef int ew_status;
 #define EW_ERR_UNSUPPORTED (-2)
 #define EW_ERR_HIP (-3)
 
-#define EW_ABI_VERSION 9
+#define EW_ABI_VERSION 10
 int ew_abi_version(void);
 const char* ew_last_error(void);
 
@@ -193,6 +193,15 @@ ew_status ew_groupnorm_finalize(float* ws, int n_slabs, int rows, int C_tot, int
 ew_status ew_groupnorm_apply_f16(const void* x, const void* x_lo, const float* ws, const void* gamma, const void* beta,
                                  void* y, int n_slabs, int rows, int C_src, int c_off, int C_tot, int groups, float eps,
                                  int silu, void* stream);
+/* Split-operand form of the apply (ABI 10): with f the fp32 result, y = fp16(f) and y_lo = fp16(f - float(y)), both with row stride ld_y
+ * (>= C_tot).  y_lo = y + C_tot with ld_y = 2 * C_tot gives rows [x_hi | x_lo]: the A operand of a consumer whose weights are packed
+ * [W_hi | W_hi | W_lo] over three K blocks (second source a2 = a, c2 = C_tot), i.e. x W formed to ~2^-21 in both operands.  Used where the
+ * per-group energy analysis (tests/analysis_fp16_floor.py --per-group) puts a large share of the fp16 operand-rounding distance to the
+ * reference's fp32 result in layers that are < 1 % of the flops: conv_norm_out -> conv_out (unet_plucker.py:236, 478-480) and the
+ * level-0 TransformerSpatioTemporalModel.norm -> proj_in. */
+ew_status ew_groupnorm_apply_split_f16(const void* x, const void* x_lo, const float* ws, const void* gamma, const void* beta,
+                                       void* y, void* y_lo, int ld_y, int n_slabs, int rows, int C_src, int c_off, int C_tot,
+                                       int groups, float eps, int silu, void* stream);
 
 /* LayerNorm over the last dim (fp16 in/out, fp32 two-pass statistics).  x_lo (may be NULL): lo8 companion of a split
  * residual stream (int8).  Optional fused pre-add: x' = x + addvec[row / rows_per_group][:] is what gets normalised, and x' is
@@ -242,6 +251,12 @@ ew_status ew_nhwc_f16_to_nchw_f32(const void* x, float* y, int N, int C, int H, 
  * evoworld/trainer/unet_plucker.py:131-136); its two fp16 roundings were 12-15 % each of the build's squared distance to the fp32 oracle. */
 ew_status ew_nchw_f32_to_nhwc_split_f16(const float* x, void* y, int N, int C, int H, int W, int ldc, int c_off, int lo_off,
                                         int dup_off, float scale, void* stream);
+
+/* Sinusoidal embedding of scalars (ABI 10): out fp16 [n_rows, dim] = [cos(v f_j) | sin(v f_j)], j < dim / 2, f_j = exp(-ln(10000) j / (dim / 2)),
+ * v = vals[row % n_vals] (device fp32).  diffusers `Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)` as the reference's U-Net applies it
+ * to the timestep and to the three added time ids in every forward (evoworld/trainer/unet_plucker.py:395-420): two launches per forward instead of
+ * the arange / exp / mul / cos / sin / cat chain of torch elementwise kernels. */
+ew_status ew_sinusoid_embed_f16(const float* vals, int n_vals, int n_rows, int dim, void* out, void* stream);
 
 /* Fused denoise-step glue: CFG combine + Euler (v-prediction) step + scale_model_input + concat for the next
  * step.  eps: fp16 NHWC [2*T, h, w, ld_eps] (rows [0,T) uncond, [T,2T) cond; first 4 channels);
@@ -325,7 +340,8 @@ ew_status ew_filter_compact(const float* conf, size_t n, float thr, const float*
 /* Point splat into cubemap z-buffers: for view v, face f: p_cam = w2c[v][f] * p; u = fx*x/z+cx, ...;
  * nearest pixel, min depth wins (64-bit atomicMin of depth-bits<<32 | point index -> deterministic winner), z > near.
  * Every point is read once (16-byte loads) and tested against all V*6 matrices (wave-uniform, in SGPRs); fragments that a
- * relaxed read of the cell already beats skip the atomic.  zbuf: uint64 [V,6,res,res] pre-filled with 0xFF..FF.
+ * relaxed read of the cell already beats skip the atomic.  zbuf: uint64 [V,6,res,res], 16-byte aligned, UNINITIALISED on entry: since
+ * ABI 10 the call itself sets every cell to 0xFF..FF ("no fragment") before the splat (ABI <= 9: the caller pre-filled it).
  * ew_splat_resolve writes the winners' colours (0 background): rgb = packed RGB bytes (rgb_stride 3) or RGBX words
  * (rgb_stride 4, as ew_filter_compact emits); faces uint8 [V,6,res,res,face_channels] (3 | 4).
  * Replaces Open3D OffscreenRenderer point rendering driven by render_face/render_cubemap,

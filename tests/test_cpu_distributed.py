@@ -24,8 +24,10 @@ def _worker(rank, world, port, q):
     wts = [torch.arange(6, dtype=torch.float32) * (1 if r == 0 else 0)]
     D.broadcast_tensors(wts, src=0)
     t = D.max_over_ranks(1.0 + r, "cpu")
+    per_rank = D.gather_floats(10.0 + r, "cpu")
+    info = D.world_info()
     D.barrier()
-    q.put((r, mine, [float(g.mean()) for g in got], wts[0].tolist(), t))
+    q.put((r, mine, [float(g.mean()) for g in got], wts[0].tolist(), t, per_rank, info))
 
 
 def test_two_rank_gloo_shard_and_gather():
@@ -42,12 +44,14 @@ def test_two_rank_gloo_shard_and_gather():
     assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3]
     for r in res:
         assert r[2] == [1.0, 2.0] and r[3] == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0] and r[4] == 2.0
+        assert r[5] == [10.0, 11.0] and r[6] == (2, "gloo")      # bench.py's per_rank_ms_per_step / rccl_world + dist_backend fields
 
 
 def test_single_process_helpers_are_noops():
     from evoworld_amd import distributed as D
     x = torch.ones(2)
     assert D.gather_results(x)[0] is x and D.shard_clips(3, 0, 1) == [0, 1, 2] and D.max_over_ranks(3.0, "cpu") == 3.0
+    assert D.gather_floats(2.5, "cpu") == [2.5] and D.world_info() == (1, None)
 
 
 def _cfg_worker(rank, world, port, q):

