@@ -143,10 +143,10 @@ def kernel_breakdown(unet, pipe, latents, image_latents, ehs, plucker, T, h, w, 
     from evoworld_amd import _lib
     lib = _lib.load()
     rec = []
-    names = ("ew_gemm_f16", "ew_groupnorm_stats_f16", "ew_groupnorm_finalize", "ew_groupnorm_apply_f16", "ew_layernorm_f16",
+    names = ("ew_gemm_f16", "ew_groupnorm_stats_f16", "ew_groupnorm_finalize", "ew_groupnorm_apply_f16", "ew_groupnorm_apply_split_f16", "ew_layernorm_f16",
              "ew_attn_spatial_f16", "ew_attn_spatial_log2_f16", "ew_attn_temporal_f16", "ew_ff_geglu320_f16")
     kname = {"ew_groupnorm_stats_f16": "gn_stats_kernel", "ew_groupnorm_finalize": "gn_finalize_kernel",
-             "ew_groupnorm_apply_f16": "gn_apply_kernel",
+             "ew_groupnorm_apply_f16": "gn_apply_kernel", "ew_groupnorm_apply_split_f16": "gn_apply_kernel",
              "ew_layernorm_f16": "ln_kernel", "ew_attn_spatial_f16": "attn_spatial_kernel", "ew_attn_spatial_log2_f16": "attn_spatial_kernel",
              "ew_attn_temporal_f16": "attn_temporal_kernel", "ew_ff_geglu320_f16": "ff320_kernel"}
     orig = {n: getattr(lib, n) for n in names}
@@ -172,8 +172,8 @@ def kernel_breakdown(unet, pipe, latents, image_latents, ehs, plucker, T, h, w, 
                     if n == "ew_layernorm_f16":
                         key += f" rows={a[9]} C={a[10]}"
                     elif n.startswith("ew_groupnorm") and n != "ew_groupnorm_finalize":
-                        o_ = 6 if n.endswith('apply_f16') else 3
-                        key += f" slabs={a[o_]} rows={a[o_ + 1]} C={a[o_ + 2]}" + (" +lo" if a[1] else "")
+                        o_ = 8 if n.endswith('apply_split_f16') else (6 if n.endswith('apply_f16') else 3)
+                        key += f" slabs={a[o_]} rows={a[o_ + 1]} C={a[o_ + 2]}" + (" +lo" if a[1] else "") + (" +split out" if n.endswith('apply_split_f16') else "")
                     elif n.startswith("ew_attn_spatial"):
                         key += f" S={a[5]}"
                 if n.startswith("ew_attn_spatial"):

@@ -11,7 +11,7 @@ import torch  # noqa: F401  MUST precede the CDLL below: torch bundles its own l
 from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("EW_LIB_PATH") or os.path.join(_HERE, "libevoworld_hip.so")   # EW_LIB_PATH: ablation builds (tools/)
+LIB_PATH = os.environ.get("EW_LIB_PATH") or os.path.join(_HERE, "libevoworld_hip.so")   # EW_LIB_PATH: another build of the same ABI (A/B tools)
 ABI_VERSION = 10
 
 # every symbol declared in include/evoworld_hip.h
@@ -22,13 +22,10 @@ SYMBOLS = [
     "ew_depth_unproject", "ew_select_workspace_bytes", "ew_select_kth_f32", "ew_filter_compact_workspace_bytes",
     "ew_filter_compact", "ew_splat_cubemap", "ew_splat_resolve", "ew_equi2pers", "ew_resize_aa_u8",
     "ew_u8_hwc_to_f32_chw", "ew_f32_chw_to_u8_hwc", "ew_blur_axis_f32", "ew_bicubic_resize_f32", "ew_vit_patchify_f16",
-    "ew_attn_small_f16", "ew_quant_rows_fp8", "ew_gemm_fp8",
+    "ew_attn_small_f16",
     "ew_set_cu_budget", "ew_get_cu_budget", "ew_stream_create_cu_mask", "ew_stream_destroy",
     "ew_nchw_f32_to_nhwc_split_f16", "ew_euler_cfg_step_split", "ew_groupnorm_apply_split_f16", "ew_sinusoid_embed_f16",
 ]
-# entry points newer than ABI 7: an older build of the library loaded for an A/B (EW_LIB_PATH, tools/ab_lib.sh) may lack them
-_NEWER_THAN_ABI7 = {"ew_set_cu_budget", "ew_get_cu_budget", "ew_stream_create_cu_mask", "ew_stream_destroy",      # ABI 8
-                    "ew_nchw_f32_to_nhwc_split_f16", "ew_euler_cfg_step_split"}                                     # ABI 9
 
 
 class GemmArgs(ctypes.Structure):
@@ -52,8 +49,6 @@ class FfArgs(ctypes.Structure):
         ("r1", c_void_p), ("r1_lo", c_void_p), ("r2", c_void_p), ("r2_lo", c_void_p), ("out", c_void_p), ("out_lo", c_void_p),
         ("zero_page", c_void_p), ("M", c_int), ("C", c_int), ("hidden", c_int), ("rows_per_group", c_int), ("ld_rowbias", c_int),
         ("c_acc", c_float), ("c_r1", c_float), ("c_r2", c_float),
-        ("x_lo", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("addvec", c_void_p), ("add_rows_per_group", c_int),
-        ("ln_eps", c_float), ("ln_folded", c_int),
     ]
 
 
@@ -74,14 +69,13 @@ def load():
             f"{LIB_PATH} not found: build it with `make -C evoworld_amd/csrc` (hipcc --offload-arch=gfx950). "
             "evoworld_amd has no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
-    ablation = bool(os.environ.get("EW_LIB_PATH"))          # A/B against an older build of the library (tools/ab_lib.sh): ABI 7 / 8 are accepted there
-    for s in SYMBOLS:
-        if not hasattr(lib, s) and not (ablation and s in _NEWER_THAN_ABI7):
+    for s in SYMBOLS:       # (EW_LIB_PATH: another BUILD of the same ABI -- A/B of two compilations in one gpurun call; older ABIs are refused)
+        if not hasattr(lib, s):
             raise EvoWorldHipError(f"{LIB_PATH} does not export {s}")
     lib.ew_last_error.restype = c_char_p
     lib.ew_gemm_last_kernel.restype = c_char_p
     lib.ew_abi_version.restype = c_int
-    if lib.ew_abi_version() != ABI_VERSION and not (ablation and lib.ew_abi_version() in (7, 8)):
+    if lib.ew_abi_version() != ABI_VERSION:
         raise EvoWorldHipError(f"ABI mismatch: library {lib.ew_abi_version()} != binding {ABI_VERSION}")
     P, I, F, LL = c_void_p, c_int, c_float, c_longlong
     sig = {
@@ -119,8 +113,6 @@ def load():
         "ew_bicubic_resize_f32": [P, P, I, I, I, I, I, I, P, P, P],
         "ew_vit_patchify_f16": [P, P, I, I, I, I, P],
         "ew_attn_small_f16": [P, P, P, P, I, I, I, I, I, I, F, P],
-        "ew_quant_rows_fp8": [P, P, P, I, I, P],
-        "ew_gemm_fp8": [P, P, P, P, P, I, I, I, LL, P],
     }
     lib.ew_groupnorm_workspace_floats.argtypes = [c_int, c_int, c_int, c_int]
     lib.ew_groupnorm_workspace_floats.restype = c_size_t
@@ -135,19 +127,14 @@ def load():
     lib.ew_gemm_streamk_status.restype = c_int
     lib.ew_set_gemm_debug.argtypes = [c_int]
     lib.ew_set_gemm_debug.restype = None
-    if hasattr(lib, "ew_set_cu_budget"):
-        lib.ew_set_cu_budget.argtypes, lib.ew_set_cu_budget.restype = [c_int], c_int
-        lib.ew_get_cu_budget.argtypes, lib.ew_get_cu_budget.restype = [], c_int
-        lib.ew_stream_create_cu_mask.argtypes, lib.ew_stream_create_cu_mask.restype = [c_int, c_int], c_void_p
-        lib.ew_stream_destroy.argtypes, lib.ew_stream_destroy.restype = [c_void_p], c_int
+    lib.ew_set_cu_budget.argtypes, lib.ew_set_cu_budget.restype = [c_int], c_int
+    lib.ew_get_cu_budget.argtypes, lib.ew_get_cu_budget.restype = [], c_int
+    lib.ew_stream_create_cu_mask.argtypes, lib.ew_stream_create_cu_mask.restype = [c_int, c_int], c_void_p
+    lib.ew_stream_destroy.argtypes, lib.ew_stream_destroy.restype = [c_void_p], c_int
     for name, argtypes in sig.items():
-        if ablation and name in _NEWER_THAN_ABI7 and not hasattr(lib, name):
-            continue
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = c_int
-    if os.environ.get("EW_GEMM_DEBUG"):            # measurement switches (tools/experiments), never set in production
-        lib.ew_set_gemm_debug(int(os.environ["EW_GEMM_DEBUG"]))
     _lib = lib
     return lib
 

@@ -22,35 +22,6 @@
 // plain issues anyway, and beside MFMAs it costs MORE than that (tools/experiments/mb_mfma_valu.hip: 8 MFMA + 32 v_pk_fma 308 ns,
 // 8 MFMA + 64 v_fma 255 ns per iteration).  Bit-identical results, 840 -> 855 TF/s at the level-0 shape.  The file is compiled with
 // -fno-slp-vectorize so that hipcc does not re-pack them.
-#ifndef EW_ATTN_SCALAR_FMA
-#define EW_ATTN_SCALAR_FMA 1
-#endif
-#ifndef EW_ATTN_PRIO
-#define EW_ATTN_PRIO 0       /* A/B: 1 = s_setprio 1 around the QK^T MFMA cluster, 2 = around the P.V cluster too */
-#endif
-#ifndef EW_ATTN_ROWSUM
-#define EW_ATTN_ROWSUM 0     /* 0: v_dot2c of the fp16-rounded P (round-toward-zero pack); 1: f32 adds of the exponentials + round-to-nearest pack (A/B, round 4) */
-#endif
-#ifndef EW_ATTN_LAZYMAX
-#define EW_ATTN_LAZYMAX 1    /* round 5 (log2 form only): no per-tile max in the hot path -- a tile's row sum (which the normaliser needs anyway) tells whether
-                                any of its exponentials left the safe range; only then, and on a sequence's first tile, the max chain + rescale run */
-#endif
-#ifndef EW_ATTN_EARLY_WRITE
-#define EW_ATTN_EARLY_WRITE 1   /* round 5: the s_memtime anatomy (profiles/r05_g_exp47_attn_cycle_anatomy.txt) showed 650 of a tile's 3600 clocks per wave waiting for the
-                                   NEXT tile's K / V loads (requested at the top of the tile, stored to LDS at its end: ~0.8 of a tile period in flight).  The other LDS buffer
-                                   is free from the barrier that opens the tile, so tile j+1 is stored at the TOP of tile j and the registers take tile j+2 at once: a full
-                                   tile period in flight, no extra registers, no extra LDS */
-#endif
-#ifndef EW_ATTN_VW64
-#define EW_ATTN_VW64 1       /* round 5: V^T tile written as four ds_write_b64 straight from the loaded registers instead of eight v_mov + two ds_write_b128 */
-#endif
-#ifdef EW_ATTN_TRACE       /* instrumented build (make attn_trace; tools/experiments/exp47_attn_trace.py): s_memtime stamps of one workgroup, 6 per 64-key tile and wave */
-#define ATTN_TRACE_ARG , unsigned long long* trace
-#define ATTN_STAMP(k) do { if (trace && blockIdx.x == 4001 && lane == 0 && j < 256) trace[((size_t)j * 4 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define ATTN_TRACE_ARG
-#define ATTN_STAMP(k) do {} while (0)
-#endif
 namespace {
 
 __device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
@@ -61,14 +32,11 @@ typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
 // subtracted by the MFMA itself: the first MFMA of a score block takes C = (-m, ..., -m) (a 16-register tuple that only changes when the
 // deferred max is raised) instead of C = 0.  The per-score v_fma_f32 (32 of the ~120 VALU instructions of a 64-key tile in this VALU-bound
 // loop) disappears; a raise (rare) subtracts the increment from the tile's scores afterwards.
-#ifndef EW_ATTN_PRE_BLOCKS
-#define EW_ATTN_PRE_BLOCKS 3   /* 168 VGPRs (3 dwords of scratch outside the tile loop) -> 3 waves per SIMD: 926 vs 875 TF/s at the level-0 shape */
-#endif
 template <bool PRE>
-__global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatial_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+__global__ __launch_bounds__(256, PRE ? 3 : 2) void attn_spatial_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                                const f16* __restrict__ vt, f16* __restrict__ o, int S,
                                                                int heads, int ld_qk, long long ld_vt, int ld_o, float sl2,
-                                                               int n_qtiles ATTN_TRACE_ARG) {
+                                                               int n_qtiles) {
     __shared__ __attribute__((aligned(16))) char smem[32768];  // 2 x { K tile [64 keys][64 d] | V^T tile [64 d][64 keys] }
     char* const kl = smem;
     char* const vl = smem + 8192;
@@ -130,7 +98,6 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
         *(f16x8*)(kl + k_w0) = kr0;
         *(f16x8*)(kl + k_w1) = kr1;
         // 16-key group -> slot A = keys {0..3, 8..11}, slot B = keys {4..7, 12..15}
-#if EW_ATTN_VW64
         // the loop is VALU-bound: the repack into two 16-byte registers cost eight v_mov per tile; four 8-byte LDS writes cost none
         // (inline asm: hipcc merges adjacent 8-byte LDS stores back into ds_write_b128 + the moves; the __syncthreads after every write_tile waits
         // with lgkmcnt(0) whatever the compiler tracked)
@@ -143,21 +110,12 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
         const u32x2_t v0l = {w0[0], w0[1]}, v0h = {w0[2], w0[3]}, v1l = {w1[0], w1[1]}, v1h = {w1[2], w1[3]};
         asm volatile("ds_write_b64 %0, %1 offset:%6\n\tds_write_b64 %0, %2 offset:%7\n\tds_write_b64 %3, %4 offset:%6\n\tds_write_b64 %3, %5 offset:%7"
                      :: "v"(a0), "v"(v0l), "v"(v1l), "v"(a1), "v"(v0h), "v"(v1h), "n"(VOFF), "n"(VOFF + 8) : "memory");
-#else
-        const f16x8 sa = {vr0[0], vr0[1], vr0[2], vr0[3], vr1[0], vr1[1], vr1[2], vr1[3]};
-        const f16x8 sb = {vr0[4], vr0[5], vr0[6], vr0[7], vr1[4], vr1[5], vr1[6], vr1[7]};
-        *(f16x8*)(vl + k_w0) = sa;   // same (row, slot) geometry as the K tile: row = srow (d), slots 2*sc, 2*sc+1
-        *(f16x8*)(vl + k_w1) = sb;
-#endif
     };
 
     f32x16 oacc[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
     float m_run = PRE ? 0.f : -INFINITY, l_run = 0.f;
-#if EW_ATTN_ROWSUM == 1
-    float l_run2 = 0.f;                     // second partial row sum (two independent add chains)
-#endif
     f32x16 negm;                            // PRE: C operand of the first score MFMA = -m_run in every element (0 until the first tile's raise)
 #pragma unroll
     for (int i = 0; i < 16; ++i) negm[i] = 0.f;
@@ -175,18 +133,16 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
     const int nt = (S + 63) / 64;
     load_tile(0);
     write_tile(std::integral_constant<int, 0>{});
-#if EW_ATTN_EARLY_WRITE
     if (nt > 1) {                       // tile 1 waits in the registers; tile_step(0) stores it
         kp_run += (long long)64 * ld_qk;
         vp_run += 64;
         if (128 <= S) load_tile_full(); else load_tile(64);
     }
-#endif
     __syncthreads();
     // One 64-key tile; the LDS buffer it reads (BUF) and the one it refills (BUF ^ 1) are compile-time constants: the loop is
     // unrolled by two below, so buffer selection costs no VALU (it used to be eight xors on the fragment offsets plus address
     // arithmetic on the four tile stores per iteration).
-    constexpr bool LAZY = PRE && bool(EW_ATTN_LAZYMAX) && EW_ATTN_ROWSUM == 0;
+    constexpr bool LAZY = PRE;
     constexpr float LAZY_SUM_THR = 1024.f;   // a lane's 32 exponentials of a tile may sum to 2^10 before the max is looked at (each <= 2^10: far inside fp16)
     constexpr float LAZY_RAISE_THR = 4.0f;   // ... and then every query whose tile max exceeds the running max by 2^4 is raised (a lane over the sum limit holds
                                              // an element >= 2^5, so its query always is)
@@ -196,8 +152,6 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
         const int key0 = j * 64;
         const char* kb = kl + BUF * 16384;
         const char* vb = vl + BUF * 16384;
-        ATTN_STAMP(0);
-#if EW_ATTN_EARLY_WRITE
         // the other buffer was last read in iteration j-1 and every wave has passed that barrier: tile j+1 (requested a whole tile ago) goes in now,
         // and the registers are free for tile j+2
         if (j + 1 < nt) write_tile(std::integral_constant<int, BUF ^ 1>{});
@@ -206,18 +160,8 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
             vp_run += 64;
             if (key0 + 192 <= S) load_tile_full(); else load_tile(key0 + 128);
         }
-#else
-        if (j + 1 < nt) {
-            kp_run += (long long)64 * ld_qk;
-            vp_run += 64;
-            if (key0 + 128 <= S) load_tile_full(); else load_tile(key0 + 64);
-        }
-#endif
 
         // ---- S^T = K Q^T : two 32-key blocks ----
-#if EW_ATTN_PRIO
-        __builtin_amdgcn_s_setprio(1);      // A/B (round 4, guide T5): favour the wave that is entering an MFMA cluster
-#endif
         f32x16 sacc[2];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
@@ -233,10 +177,6 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
                 sacc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[blk], 0, 0, 0);
             }
         }
-#if EW_ATTN_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        ATTN_STAMP(1);
         // ---- mask the ragged last tile ----
         if (key0 + 64 > S) {
 #pragma unroll
@@ -289,9 +229,6 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
                 const float alpha = j == 0 ? 1.f : exp2f(-delta);           // nothing accumulated yet on the first tile (exp2(-delta) may be inf)
                 m_run += delta;
                 l_run *= alpha;
-#if EW_ATTN_ROWSUM == 1
-                l_run2 *= alpha;
-#endif
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
 #pragma unroll
@@ -305,9 +242,6 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
             const float alpha = exp2f(m_run - m_new);       // 1 for the lanes that keep their max; 0 on the first tile
             m_run = m_new;
             l_run *= alpha;
-#if EW_ATTN_ROWSUM == 1
-            l_run2 *= alpha;
-#endif
 #pragma unroll
             for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
         }
@@ -328,27 +262,11 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = g2 * 8 + e * 2;
-#if EW_ATTN_SCALAR_FMA
                     const float t[2] = {PRE ? sacc[blk][r] : fmaf(sacc[blk][r], sl2, nm2[0]), PRE ? sacc[blk][r + 1] : fmaf(sacc[blk][r + 1], sl2, nm2[0])};
-#else
-                    static_assert(!PRE, "EW_ATTN_SCALAR_FMA=0 (packed-fma ablation) is only valid without the log2 pre-scaling: with PRE the MFMA C operand has already subtracted the running max");
-                    const f32x2 sv = {sacc[blk][r], sacc[blk][r + 1]};
-                    const f32x2 t = __builtin_elementwise_fma(sv, sl22, nm2);          // v_pk_fma_f32: two scores per VALU issue
-#endif
-#if EW_ATTN_ROWSUM == 1
-                    // row sums as plain f32 adds of the UNROUNDED exponentials (MI355X_MICROARCH: a v_dot2c beside MFMAs costs ~10 cycles
-                    // beyond its issue slot); P is then packed round-to-nearest so that its rounding stays unbiased against that normaliser
-                    const float e0 = __builtin_amdgcn_exp2f(t[0]), e1 = __builtin_amdgcn_exp2f(t[1]);
-                    typedef float f2_t __attribute__((ext_vector_type(2)));
-                    const f2_t ev = {e0, e1};
-                    const h2_t ph = __builtin_convertvector(ev, h2_t);
-                    if (e & 1) l_run2 += e0 + e1; else l_run += e0 + e1;
-#else
                     const h2_t ph = __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]));
                     const h2_t one = {(__fp16)1.0f, (__fp16)1.0f};
                     if constexpr (LAZY) lt = __builtin_amdgcn_fdot2(ph, one, lt, false);
                     else l_run = __builtin_amdgcn_fdot2(ph, one, l_run, false);
-#endif
                     w[e] = __builtin_bit_cast(unsigned, ph);
                 }
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -364,11 +282,7 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
             }
             l_run += lt;
         }
-        ATTN_STAMP(2);
         // ---- O^T += V^T P^T ----
-#if EW_ATTN_PRIO == 2
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int g = 0; g < 4; ++g) {       // 16-key group (MFMA k-step)
 #pragma unroll
@@ -377,17 +291,7 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
                 oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[g], oacc[db], 0, 0, 0);
             }
         }
-#if EW_ATTN_PRIO == 2
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        ATTN_STAMP(3);
-#if !EW_ATTN_EARLY_WRITE
-        // double-buffered tiles: the other buffer was last read in iteration j-1 (every wave passed that barrier)
-        if (j + 1 < nt) write_tile(std::integral_constant<int, BUF ^ 1>{});
-#endif
-        ATTN_STAMP(4);
         __syncthreads();
-        ATTN_STAMP(5);
     };
     if constexpr (LAZY) {
         tile_step(0, std::integral_constant<int, 0>{}, std::true_type{});
@@ -406,9 +310,6 @@ __global__ __launch_bounds__(256, PRE ? EW_ATTN_PRE_BLOCKS : 2) void attn_spatia
         if (j < nt) tile_step(j, std::integral_constant<int, 0>{}, std::false_type{});
     }
     // ---- normalise + store: lane holds query q_idx, d = 32*db + 8*(r>>2) + 4*lh + (r&3) ----
-#if EW_ATTN_ROWSUM == 1
-    l_run += l_run2;
-#endif
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     if (q_idx < S) {
@@ -681,13 +582,6 @@ __global__ __launch_bounds__(256) void attn_temporal64_kernel(const f16* __restr
 
 }  // namespace
 
-#ifdef EW_ATTN_TRACE
-static unsigned long long* g_attn_trace = nullptr;
-extern "C" void ew_attn_set_trace(void* buf) { g_attn_trace = (unsigned long long*)buf; }
-#define ATTN_TRACE_PASS , g_attn_trace
-#else
-#define ATTN_TRACE_PASS
-#endif
 static ew_status attn_spatial_launch(const void* q, const void* k, const void* vt, void* o, int n_seq, int S, int heads, int ld_qk,
                                      long long ld_vt, int ld_o, float scale, bool pre, void* stream, const char* name) {
     EW_REQUIRE(q && k && vt && o, "%s: null pointer", name);
@@ -699,11 +593,11 @@ static ew_status attn_spatial_launch(const void* q, const void* k, const void* v
     EW_REQUIRE(nblk < 0x7fffffffLL, "%s: grid too large", name);
     if (pre)
         hipLaunchKernelGGL(attn_spatial_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const f16*)q,
-                           (const f16*)k, (const f16*)vt, (f16*)o, S, heads, ld_qk, ld_vt, ld_o, 1.0f, n_qtiles ATTN_TRACE_PASS);
+                           (const f16*)k, (const f16*)vt, (f16*)o, S, heads, ld_qk, ld_vt, ld_o, 1.0f, n_qtiles);
     else
         hipLaunchKernelGGL(attn_spatial_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const f16*)q,
                            (const f16*)k, (const f16*)vt, (f16*)o, S, heads, ld_qk, ld_vt, ld_o,
-                           scale * 1.4426950408889634f, n_qtiles ATTN_TRACE_PASS);
+                           scale * 1.4426950408889634f, n_qtiles);
     return ew_check_launch(name);
 }
 

@@ -83,9 +83,6 @@ __device__ __forceinline__ f32x2 ew_vgelu2_erf(f32x2 v, f32x2 g) {
     return (v * 0.5f) * __builtin_elementwise_fma(ag, y, g);
 }
 __device__ __forceinline__ f32x2 ew_vgelu2(f32x2 v, f32x2 g) {
-#ifdef EW_GEGLU_ERF
-    return ew_vgelu2_erf(v, g);
-#else
     // k_i = -log2(e) * c_i, c = (1.59501577, 7.40112921e-2, -7.03033591e-4)
     f32x2 x2 = g * g;
     x2 = (f32x2){fminf(x2[0], 64.0f), fminf(x2[1], 64.0f)};
@@ -95,7 +92,6 @@ __device__ __forceinline__ f32x2 ew_vgelu2(f32x2 v, f32x2 g) {
     const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + (f32x2){1.0f, 1.0f};
     const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
     return (v * g) * r;
-#endif
 }
 
 // ---- split residual stream: value = (hi fp16, lo8 int8) ------------------------------------------------------------------

@@ -1,6 +1,8 @@
-// ff_fused.hip -- fused LayerNorm + GEGLU feed-forward for the 320-channel (level 0) transformer blocks, gfx950 (round 3).
+// ff_fused.hip -- fused GEGLU feed-forward for the 320-channel (level 0) transformer blocks, gfx950 (round 3).
 //
-//   out = c_acc * ( GEGLU(n W1^T + b1) W2^T + b2 + rowbias ) + c_r1 * r1 + c_r2 * r2,   n = x  or  LayerNorm(x + addvec)
+//   out = c_acc * ( GEGLU(x W1^T + b1) W2^T + b2 + rowbias ) + c_r1 * r1 + c_r2 * r2,   x = the LayerNorm output (ew_layernorm_f16)
+//   (round 6: the LayerNorm-in-the-prologue variants -- ln_gamma prologue, +9 ms per forward; folded LayerNorm, +1.1 ms -- were removed from the
+//   source; they live in git history, commit 3205fa6, and their measurements in DESIGN.md sections 3.3-3.5)
 //
 // i.e. diffusers FeedForward(dim, activation_fn="geglu") = net.0 (GEGLU proj 320 -> 2 x 1280) + net.2 (Linear 1280 -> 320) of
 // BasicTransformerBlock.ff / TemporalBasicTransformerBlock.ff / .ff_in with the LayerNorm in front of it (norm3 / norm_in;
@@ -10,9 +12,9 @@
 // Why a fused kernel: as LayerNorm + two GEMMs the 1280-wide GEGLU intermediate of level 0 (460800 x 1280 fp16 = 1.18 GB) is
 // written and read back 15 times per forward and the normalised tensor 15 times more.  Here neither leaves the chip:
 //   * one workgroup = 8 waves as 4 (M) x 2 (N), two per SIMD, on a 128-row tile.  A wave owns 32 rows; their (normalised) x
-//     fragments stay in 80 registers for the whole tile.  The LayerNorm runs on those registers (prologue).  Register
-//     budget as compiled (-Rpass-analysis=kernel-resource-usage, round 4): 256 VGPRs, 0 AGPRs, 17-55 spilled VGPRs in the
-//     plain variants (72-224 B of scratch per lane; the ln_gamma prologue variants 171-446, the folded-LayerNorm ones 34-58) --
+//     fragments stay in 80 registers for the whole tile.  Register
+//     budget as compiled (-Rpass-analysis=kernel-resource-usage, round 4): 256 VGPRs, 0 AGPRs, 17-55 spilled VGPRs
+//     (72-224 B of scratch per lane) --
 //     every scratch access sits in the per-TILE prologue / epilogue; the 40-iteration chunk loop itself holds x fragments, both
 //     accumulator sets and the W fragments in registers with zero scratch traffic (checked in the ISA: no scratch_load /
 //     scratch_store between the loop header and its back edge).  (Until round 4 the ln_gamma prologue was a run-time branch
@@ -26,7 +28,7 @@
 //     hidden indices -- the GEGLU result is already in A-fragment order;
 //   * the down-projection trails the up-projection by one chunk, so ONE barrier per chunk serves both the weight hand-over
 //     and the GEGLU exchange; the GEGLU arithmetic of chunk c-1 (VALU: two transcendentals per element) is issued between the
-//     up-projection MFMAs of chunk c (FF_GSHADOW), the DMA requests between the down-projection MFMAs;
+//     up-projection MFMAs of chunk c (1), the DMA requests between the down-projection MFMAs;
 //   * weights go through LDS one chunk image (W1 40 KB + W2 20 KB) per step, double-buffered, by LDS-DMA from host-packed
 //     images that are byte copies of the LDS layout (1 KB contiguous per DMA instruction; the XOR swizzles that make the
 //     ds_read_b128 fragment reads conflict-free are baked into the pack).  A chunk's image is requested a whole chunk before it is
@@ -42,9 +44,7 @@
 namespace {
 
 constexpr int C = 320, HID = 1280, CH = 32, NCH = HID / CH;       // 40 chunks of 32 hidden units
-#ifndef FF_WM
-#define FF_WM 4           /* waves along M: 4 -> 8 waves (2 per SIMD, 256 registers), 32 rows each; 2 -> 4 waves (1 per SIMD, 512 registers), 64 rows each */
-#endif
+constexpr int FF_WM = 4;  // waves along M: 4 -> 8 waves (2 per SIMD, 256 registers), 32 rows each (2 -> 4 waves, 1 per SIMD, 64 rows each measured 1.53 vs 1.36 ms)
 constexpr int BM = 128, WAVES_N = 2, NWV = FF_WM * WAVES_N, WROWS = BM / FF_WM, RF = WROWS / 16;
 constexpr int KS = C / 32;                                         // 10 k-steps of the up-projection
 constexpr int KT = C / 64;                                         // W1 chunk image = 5 K-tiles of [64 staged rows][64 k]
@@ -53,10 +53,7 @@ constexpr int W1_TILE = KT * W1_KT;                                // 40 KB per 
 constexpr int W2_TILE = C * CH * 2;                                // 320 staged rows x 32 k x 2 B = 20 KB per chunk
 constexpr int HX_TILE = (BM / 16) * 64 * 16;                       // GEGLU exchange: 8 row fragments x 64 lanes x 16 B = 8 KB per chunk
 constexpr int LDS_W1 = 0, LDS_W2 = 2 * W1_TILE, LDS_HX = LDS_W2 + 2 * W2_TILE, LDS_B1 = LDS_HX + 2 * HX_TILE;
-#ifndef FF_BIAS_C
-#define FF_BIAS_C 1       /* 1 (round 4): b1 sits in LDS as fp32 and enters through the C operand of a chunk's first up-projection MFMAs (no cvt / add in the GEGLU) */
-#endif
-constexpr int LDS_SCR = LDS_B1 + 2 * HID * (FF_BIAS_C ? 4 : 2);   // 4 KB scratch slot (FF_GSHADOW: GEGLU output of the no-op first slice)
+constexpr int LDS_SCR = LDS_B1 + 2 * HID * 4;             // b1 as fp32 (enters through the C operand); then a 4 KB scratch slot (GEGLU output of the no-op first slice)
 constexpr int LDS_BYTES = LDS_SCR + 64 * NWV * 8 + 4096;                    // 80 + 40 + 16 + 5 KB
 constexpr int P1 = W1_TILE / 1024 / NWV;                           // W1 DMA pieces per wave and chunk (5); W2's 20 pieces are dealt round-robin
 constexpr int P2MAX = (W2_TILE / 1024 + NWV - 1) / NWV;            // 3 (waves 4-7 issue 2)
@@ -76,13 +73,8 @@ struct FfP {
     f16* out;
     int8_t* out_lo;
     const f16* zero_page;
-    const int8_t* x_lo;      // LayerNorm prologue (ln_gamma != null): x is the stream (hi + optional lo8), + addvec[m / add_rpg] before the norm
-    const f16* ln_gamma;
-    const f16* ln_beta;
-    const f16* addvec;
-    int M, rows_per_group, ld_rowbias, n_tiles, add_rpg, stagger;
-    unsigned long long* trace;
-    float c_acc, c_r1, c_r2, ln_eps;
+    int M, rows_per_group, ld_rowbias, n_tiles;
+    float c_acc, c_r1, c_r2;
 };
 
 #define FF_FENCE() asm volatile("" ::: "memory")
@@ -91,21 +83,9 @@ struct FfP {
 // loads are issued at the end of the previous tile), which drained the weight DMA right after it was requested: 3.4x slower.
 #define FF_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)
 #define FF_PIN() __builtin_amdgcn_sched_barrier(0)
-#ifdef FF_TRACE           /* tools/experiments/exp39_ff_trace.py: s_memtime stamps of block 0, 8 per chunk and wave */
-#define FF_STAMP(k) do { if (p.trace && blockIdx.x == 0 && lane == 0 && cc < 4096) p.trace[((size_t)cc * NWV + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define FF_STAMP(k) do {} while (0)
-#endif
-#ifndef FF_GSHADOW
-#define FF_GSHADOW 1      /* GEGLU of chunk c-1 between the up-projection MFMAs of chunk c (0: in phase 2, before the down-projection) */
-#endif
 #define FF_WAIT_VM0_LGKM0() __builtin_amdgcn_s_waitcnt(0x0070)
-#ifndef FF_ABL
-#define FF_ABL 0          /* ablation builds (tools/experiments): 1 no GEGLU math, 2 no DMA, 4 no epilogue, 8 no up-proj MFMA, 16 no down-proj MFMA */
-#endif
 
-template <bool LO, bool R2, int XLO>      // XLO: 0 = x as given, 1 = ln_gamma prologue on hi + lo8, 2 = folded LayerNorm (normalise only), 3 = ln_gamma prologue on a plain fp16 x
-                                          // (the prologue code is compiled into its own variants only: its presence alone cost the plain variants ~170 spilled VGPRs)
+template <bool LO, bool R2>
 __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -113,40 +93,28 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int frow = lane & 15, fks = lane >> 4, sw = frow & 7;
-#ifndef EW_PRIO_YOUNG
-#define EW_PRIO_YOUNG 1       /* A/B (round 4: -0.3 ... -0.7 ms per forward each, profiles/r04_l_static_prio.txt): static s_setprio 1 for the second-dispatched half of the workgroup (MI355X_MICROARCH, two waves per SIMD, item 4) */
-#endif
-#if EW_PRIO_YOUNG
     if (wave >= NWV / 2) __builtin_amdgcn_s_setprio(1);
-#endif
 
     // W2 and exchange buffers start as zeros: the first chunk of a tile runs the trailing down-projection slot on a zero A
     // fragment (no branch in the pipeline), which must not meet NaN bit patterns of uninitialised LDS
     for (int i = tid; i < (2 * W2_TILE + 2 * HX_TILE) / 16; i += 64 * NWV) *(f16x8*)(smem + LDS_W2 + i * 16) = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
     // packed b1 -> LDS once (5 KB)
-#if FF_BIAS_C
     for (int i = tid; i < 2 * HID / 8; i += 64 * NWV) {
         const f16x8 b = *(const f16x8*)((const char*)p.b1p + i * 16);
 #pragma unroll
         for (int e = 0; e < 8; ++e) ((float*)(smem + LDS_B1))[i * 8 + e] = (float)b[e];
     }
-#else
-    for (int i = tid; i < 2 * HID * 2 / 16; i += 64 * NWV) *(f16x8*)(smem + LDS_B1 + i * 16) = *(const f16x8*)((const char*)p.b1p + i * 16);
-#endif
 
     const int G = gridDim.x;
     const int n_my = (p.n_tiles - (int)blockIdx.x + G - 1) / G;            // tiles blockIdx.x, +G, ...
     if (n_my <= 0) return;
     const int CC_total = n_my * NCH;
-#ifndef FF_STAGGER
-#define FF_STAGGER 16
-#endif
     // Start stagger.  All tiles cost the same, so 256 workgroups started together stay in step for the whole launch: every CU asks
     // L2 for the same 60 KB weight chunk at the same moment and every CU's epilogue (the only HBM traffic) falls into the same few
     // microseconds.  n_tiles is rarely a multiple of the grid: workgroups that own one tile fewer than the busiest have a whole tile
     // time of slack, and spend part of it up front -- (blockIdx mod 16) x ~4 us (s_sleep 127 = 8128 clocks)
-    if (FF_STAGGER > 0 && n_my < (p.n_tiles + G - 1) / G) {
-        const int d = (int)(blockIdx.x % FF_STAGGER) * p.stagger;
+    if (n_my < (p.n_tiles + G - 1) / G) {
+        const int d = (int)(blockIdx.x % 16);
         for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(127);
     }
 
@@ -188,7 +156,6 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
     // ---- x fragments of this wave's 32 rows of a tile: row frow (+16 rf), k = ks*32 + fks*8 .. +8 (both waves of an M pair hold
     // the same rows).  The NEXT tile's fragments are requested before the epilogue of the current one.
     f16x8 xf[RF][KS];
-    u32x2 xl[RF][XLO == 1 ? KS : 1];            // lo8 companions of the LayerNorm input stream
     auto load_x = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
         for (int rf = 0; rf < RF; ++rf) {
@@ -196,116 +163,6 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
             const f16* xp = p.x + (size_t)m * C + fks * 8;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) xf[rf][ks] = *(const f16x8*)(xp + ks * 32);
-            if constexpr (XLO == 1) {
-                const int8_t* lp = p.x_lo + (size_t)m * C + fks * 8;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) xl[rf][ks] = *(const u32x2*)(lp + ks * 32);
-            }
-        }
-    };
-    // LayerNorm prologue, in place on the fragments (torch.nn.LayerNorm of BasicTransformerBlock.norm3 / TemporalBasicTransformerBlock
-    // .norm_in / .norm3; same arithmetic as ew_layernorm_f16: fp32 two-pass mean / variance over the decoded stream values (+ the
-    // per-frame add vector), ((v - mean) * rstd) * gamma + beta rounded to fp16).  A row's 320 values sit in the 4 lanes
-    // (frow, fks = 0..3) x 10 fragments x 8: the values are re-decoded in each pass instead of being kept in fp32.
-    auto ln_x = [&](int tile) __attribute__((always_inline)) {
-#pragma unroll
-        for (int rf = 0; rf < RF; ++rf) {
-            const int m = min(tile * BM + wm * WROWS + rf * 16 + frow, p.M - 1);
-            const f16* ap = p.addvec ? p.addvec + (size_t)(m / p.add_rpg) * C + fks * 8 : p.zero_page;
-            const int ma = p.addvec ? 1 : 0;
-            auto val = [&](int ks, float (&v)[8]) __attribute__((always_inline)) {
-                const f16x8 av = *(const f16x8*)(ap + ks * 32 * ma);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float t;
-                    if constexpr (XLO == 1) t = ew_split_dec(xf[rf][ks][e], ew_sbyte(xl[rf][ks][e >> 2], e & 3));
-                    else t = (float)xf[rf][ks][e];
-                    v[e] = t + (float)av[e];
-                }
-            };
-            float sum = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                float v[8];
-                val(ks, v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sum += v[e];
-            }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            const float mean = sum * (1.0f / C);
-            float sq = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                float v[8];
-                val(ks, v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; sq = fmaf(d, d, sq); }
-            }
-            sq += __shfl_xor(sq, 16, 64);
-            sq += __shfl_xor(sq, 32, 64);
-            const float rstd = rsqrtf(sq * (1.0f / C) + p.ln_eps);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                float v[8];
-                val(ks, v);
-                const f16x8 gm = *(const f16x8*)(p.ln_gamma + ks * 32 + fks * 8), bt = *(const f16x8*)(p.ln_beta + ks * 32 + fks * 8);
-                f16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (f16)((v[e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
-                xf[rf][ks] = o;
-            }
-        }
-    };
-    // Folded LayerNorm (XLO == 2, round 4): gamma / beta live in the packs (W1 diag(gamma), b1 + W1 beta), so the prologue is pure
-    // register arithmetic on the fragments -- two-pass fp32 statistics over the row's 320 fp16 values (4 lanes x 80), normalise in place.
-    auto norm_x = [&]() __attribute__((always_inline)) {
-        // Every pass re-converts from the packed fragments through an OPAQUE copy: left to itself hipcc converts the 160 values of a
-        // lane to fp32 once and keeps them across the three passes (160 more live registers -> ~150 scratch round trips per tile,
-        // each draining the weight-DMA queue: measured +0.38 ms per launch, profiles/r04_i_ff_folded_ln.txt).
-        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-        // (dword by dword: an inline-asm "+v" operand wider than 32 bits is mis-compiled by this hipcc -- all four lanes of the vector
-        // came back as its first dword)
-        auto opaque = [](const f16x8 x) __attribute__((always_inline)) {
-            u32x4v w = __builtin_bit_cast(u32x4v, x);
-            unsigned a = w[0], b = w[1], c = w[2], d = w[3];
-            asm volatile("" : "+v"(a));
-            asm volatile("" : "+v"(b));
-            asm volatile("" : "+v"(c));
-            asm volatile("" : "+v"(d));
-            return (u32x4v){a, b, c, d};
-        };
-#pragma unroll
-        for (int rf = 0; rf < RF; ++rf) {
-            float sum = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const f16x8 v = __builtin_bit_cast(f16x8, opaque(xf[rf][ks]));
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sum += (float)v[e];
-            }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            const float mean = sum * (1.0f / C);
-            float sq = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const f16x8 v = __builtin_bit_cast(f16x8, opaque(xf[rf][ks]));
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = (float)v[e] - mean; sq = fmaf(d, d, sq); }
-            }
-            sq += __shfl_xor(sq, 16, 64);
-            sq += __shfl_xor(sq, 32, 64);
-            const float rstd = rsqrtf(sq * (1.0f / C) + p.ln_eps);
-            const float nmr = -mean * rstd;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const f16x8 v = __builtin_bit_cast(f16x8, opaque(xf[rf][ks]));
-                f16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (f16)fmaf((float)v[e], rstd, nmr);
-                xf[rf][ks] = o;
-            }
         }
     };
     load_x((int)blockIdx.x);
@@ -314,14 +171,13 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
     for (int ti = 0; ti < n_my; ++ti) {
         const int tile = (int)blockIdx.x + ti * G;
         const int m_w0 = tile * BM + wm * WROWS;
-        if constexpr (XLO == 2) norm_x(); else if constexpr (XLO == 1 || XLO == 3) ln_x(tile);
         f32x4 acc2[RF][NJ2];
 #pragma unroll
         for (int rf = 0; rf < RF; ++rf)
 #pragma unroll
             for (int jj = 0; jj < NJ2; ++jj) acc2[rf][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
         f16x8 hf_old[RF] = {};                  // complete GEGLU A fragments of the previous chunk (zero before the tile's first)
-        f32x4 acc1p[RF][2] = {};                // FF_GSHADOW: up-projection accumulators of the previous chunk, waiting for their GEGLU
+        f32x4 acc1p[RF][2] = {};                // 1: up-projection accumulators of the previous chunk, waiting for their GEGLU
 
         // Software pipeline over the chunks of the tile.  Iteration c:
         //   phase 1: up-projection of chunk c, this wave's half (40 MFMAs; W1 fragments two k-steps ahead), with the GEGLU of chunk c-1
@@ -337,20 +193,9 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
         // halves (ping-pong, two barriers per chunk) measured 12 % slower, scalar instead of packed fp32 GEGLU 3 % slower.
         // bias + GEGLU of one row fragment of this wave's half chunk: fragments (value 2 wn, gate 2 wn + 1) -> hidden 8 fks + 4 wn + e
         auto geglu_rf = [&](const f32x4 (&a)[2], const char* bb, char* dst) __attribute__((always_inline)) {
-#if FF_BIAS_C
             const f32x4 va = a[0], gg = a[1];          // the bias came in through the accumulators' initial value
-#else
-            const f16x4 bv = *(const f16x4*)bb, bg = *(const f16x4*)(bb + 32);
-            const f32x4 va = a[0] + (f32x4){(float)bv[0], (float)bv[1], (float)bv[2], (float)bv[3]};
-            const f32x4 gg = a[1] + (f32x4){(float)bg[0], (float)bg[1], (float)bg[2], (float)bg[3]};
-#endif
-#if FF_ABL & 1
-            const f32x2 o01 = (f32x2){va[0], va[1]} * (f32x2){gg[0], gg[1]};
-            const f32x2 o23 = (f32x2){va[2], va[3]} * (f32x2){gg[2], gg[3]};
-#else
             const f32x2 o01 = ew_vgelu2((f32x2){va[0], va[1]}, (f32x2){gg[0], gg[1]});
             const f32x2 o23 = ew_vgelu2((f32x2){va[2], va[3]}, (f32x2){gg[2], gg[3]});
-#endif
             const f16x4 o4 = {(f16)o01[0], (f16)o01[1], (f16)o23[0], (f16)o23[1]};
             *(f16x4*)dst = o4;
         };
@@ -359,21 +204,13 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
             const char* w1n = smem + LDS_W1 + ((cc + 1) & 1) * W1_TILE;
             const char* w2b = smem + LDS_W2 + ((cc + 1) & 1) * W2_TILE;       // W2(cc - 1)
             f32x4 acc1[RF][2];
-#if FF_BIAS_C
             {   // this chunk's bias (value fragment, gate fragment: 4 consecutive hidden units of this lane each) = the C operand
                 const char* bc = smem + LDS_B1 + (c * 64 + 2 * wn * 16 + fks * 4) * 4;
                 const f32x4 b0 = *(const f32x4*)bc, b1v = *(const f32x4*)(bc + 64);
 #pragma unroll
                 for (int rf = 0; rf < RF; ++rf) { acc1[rf][0] = b0; acc1[rf][1] = b1v; }
             }
-#else
-#pragma unroll
-            for (int rf = 0; rf < RF; ++rf)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc1[rf][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#endif
-            FF_STAMP(0);
-            // FF_GSHADOW: the GEGLU of the PREVIOUS chunk (VALU, ~90 instructions with two transcendentals per element) is issued between
+            // 1: the GEGLU of the PREVIOUS chunk (VALU, ~90 instructions with two transcendentals per element) is issued between
             // the up-projection MFMAs of this one, one row fragment per half of the k loop; its halves go to exchange buffer (cc - 1) & 1 and are
             // complete at this chunk's barrier.  On the first chunk of a tile the accumulators are zeros and the result goes to a scratch slot.
             [[maybe_unused]] const char* bbp = smem + LDS_B1 + ((c > 0 ? c - 1 : 0) * 64 + 2 * wn * 16 + fks * 4) * 2;
@@ -389,12 +226,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int rf = 0; rf < RF; ++rf)
-#if FF_ABL & 8
-                        asm volatile("" ::"v"(wf[ks % 3][j]), "v"(xf[rf][ks]));
-#else
                         acc1[rf][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks % 3][j], xf[rf][ks], acc1[rf][j], 0, 0, 0);
-#endif
-#if FF_GSHADOW
                 static_assert(RF == 2 || RF == 4, "GEGLU slices");
                 if constexpr (RF == 2) {
                     if (ks == 1) geglu_rf(acc1p[0], bbp, hxp);
@@ -402,24 +234,14 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
                 } else {
                     if (ks == 1 || ks == 3 || ks == 5 || ks == 7) geglu_rf(acc1p[(ks - 1) / 2], bbp, hxp + ((ks - 1) / 2) * 1024);
                 }
-#endif
                 FF_PIN();
             }
-#if FF_GSHADOW
 #pragma unroll
             for (int rf = 0; rf < RF; ++rf) { acc1p[rf][0] = acc1[rf][0]; acc1p[rf][1] = acc1[rf][1]; }
-#endif
-            FF_STAMP(1);
-#if FF_GSHADOW
             FF_WAIT_VM0_LGKM0();
-#else
-            FF_WAIT_VM0();
-#endif
-            FF_STAMP(2);
             FF_FENCE();
             __builtin_amdgcn_s_barrier();
             FF_FENCE();
-            FF_STAMP(3);
             // ---- phase 2 (no branches: on the first chunk of a tile the exchange buffer holds zeros -- see the flush -- and past the
             // end of the block's work the W1 request / fragment reads touch buffers nobody reads again)
             if (c > 0) {
@@ -435,16 +257,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
             char* d1 = smem + LDS_W1 + (cc & 1) * W1_TILE + wave * (P1 * 1024);
             const f16* s2 = (const f16*)((const char*)p.w2p + (size_t)c * W2_TILE + wave * 1024) + lane * 8;
             char* d2 = smem + LDS_W2 + (cc & 1) * W2_TILE + wave * 1024;
-#if !FF_GSHADOW
-            // ---- bias + GEGLU of this wave's half chunk -> exchange buffer cc & 1
-            {
-                const char* bb = smem + LDS_B1 + (c * 64 + 2 * wn * 16 + fks * 4) * 2;
-#pragma unroll
-                for (int rf = 0; rf < RF; ++rf) geglu_rf(acc1[rf], bb, smem + LDS_HX + (cc & 1) * HX_TILE + hx_off + rf * 1024 + wn * 8);
-            }
-#endif
             FF_PIN();
-            FF_STAMP(4);
             // ---- down-projection of chunk c-1: one k-step x this wave's 10 output fragments x 2 row fragments
 #pragma unroll
             for (int g2 = 0; g2 < 2; ++g2) {
@@ -456,29 +269,21 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
                 for (int u = 0; u < 5; ++u)
 #pragma unroll
                     for (int rf = 0; rf < RF; ++rf)
-#if FF_ABL & 16
-                        asm volatile("" ::"v"(w2f[u]), "v"(hf_old[rf]));
-#else
                         acc2[rf][g2 * 5 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[u], hf_old[rf], acc2[rf][g2 * 5 + u], 0, 0, 0);
-#endif
                 FF_PIN();
                 // DMA pieces of this wave, half per group
                 constexpr int PER = (P1 + P2MAX + 1) / 2;
 #pragma unroll
                 for (int k = g2 * PER; k < g2 * PER + PER && k < P1 + P2MAX; ++k) {
-#if !(FF_ABL & 2)
                     if (k < P1) glds16(s1 + k * 512, d1 + k * 1024);
                     else if (wave + NWV * (k - P1) < W2_TILE / 1024) glds16(s2 + (k - P1) * NWV * 512, d2 + (k - P1) * NWV * 1024);
-#endif
                 }
                 FF_PIN();
             }
-            FF_STAMP(5);
         }
         // ---- flush: down-projection of the tile's last chunk (its W2 image was requested in the last phase 2, its exchange halves
         // were written there); the exchange buffer the NEXT tile's first chunk will read as "chunk -1" is zeroed
         {
-#if FF_GSHADOW
             {   // GEGLU of the tile's last chunk (nothing left to hide it under)
                 const char* bb = smem + LDS_B1 + ((NCH - 1) * 64 + 2 * wn * 16 + fks * 4) * 2;
 #pragma unroll
@@ -488,7 +293,6 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
                     acc1p[rf][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
-#endif
             FF_WAIT_VM0_LGKM0();
             FF_FENCE();
             __builtin_amdgcn_s_barrier();
@@ -519,12 +323,6 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
             const int mrb = p.rowbias ? 1 : 0, m1 = p.r1 ? 1 : 0, m2 = p.r2 ? 1 : 0, m1l = p.r1_lo ? 1 : 0, m2l = p.r2_lo ? 1 : 0;
             constexpr int NQ = NJ2 / 2;
             const int n_w0 = wn * (C / WAVES_N) + fks * 8;
-#if FF_ABL & 4
-#pragma unroll
-            for (int rf = 0; rf < RF; ++rf)
-#pragma unroll
-                for (int jj = 0; jj < NJ2; ++jj) asm volatile("" ::"v"(acc2[rf][jj]));
-#else
 #pragma unroll
             for (int rf = 0; rf < RF; ++rf) {
                 const int m = m_w0 + rf * 16 + frow;
@@ -574,7 +372,6 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
                     }
                 }
             }
-#endif
         }
         FF_WAIT_VM0();      // next tile's x fragments (and this tile's stores) are complete before the chunk loop starts
     }
@@ -583,10 +380,6 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
 
 }  // namespace
 
-#ifdef FF_TRACE
-static unsigned long long* g_ff_trace = nullptr;
-extern "C" void ew_ff_set_trace(void* buf) { g_ff_trace = (unsigned long long*)buf; }
-#endif
 
 // Host-side layout contract of the packs (evoworld_amd/ops.py: ff_pack builds them with torch index ops):
 //   w1p  [40 chunks][5 K-tiles][64 staged rows][8 slots][8 halves]: staged row r = 16 j + i, j = 2h + vg (vg: 0 value, 1 gate),
@@ -602,9 +395,6 @@ extern "C" ew_status ew_ff_geglu320_f16(const ew_ff_args* a, void* stream) {
     EW_REQUIRE(!a->rowbias || a->ld_rowbias % 8 == 0, "ew_ff_geglu320_f16: ld_rowbias must be a multiple of 8");
     EW_REQUIRE((!a->r1_lo || a->r1) && (!a->r2_lo || a->r2), "ew_ff_geglu320_f16: r1_lo / r2_lo need r1 / r2");
     EW_REQUIRE((long long)a->M * C * 2 < (1LL << 40), "ew_ff_geglu320_f16: M too large");
-    EW_REQUIRE((a->ln_gamma != nullptr) == (a->ln_beta != nullptr), "ew_ff_geglu320_f16: ln_gamma and ln_beta go together");
-    EW_REQUIRE(a->ln_gamma || (!a->x_lo && !a->addvec), "ew_ff_geglu320_f16: x_lo / addvec need the LayerNorm prologue (ln_gamma)");
-    EW_REQUIRE(!a->ln_folded || (!a->ln_gamma && a->ln_eps > 0.f), "ew_ff_geglu320_f16: ln_folded excludes ln_gamma and needs ln_eps > 0");
     FfP p;
     p.x = (const f16*)a->x; p.w1p = (const f16*)a->w1p; p.b1p = (const f16*)a->b1p; p.w2p = (const f16*)a->w2p; p.b2 = (const f16*)a->b2;
     p.rowbias = (const f16*)a->rowbias; p.r1 = (const f16*)a->r1; p.r2 = (const f16*)a->r2;
@@ -613,38 +403,21 @@ extern "C" ew_status ew_ff_geglu320_f16(const ew_ff_args* a, void* stream) {
     p.M = a->M; p.rows_per_group = a->rows_per_group; p.ld_rowbias = a->rowbias ? a->ld_rowbias : 0;
     p.n_tiles = ew_cdiv(a->M, BM);
     p.c_acc = a->c_acc; p.c_r1 = a->r1 ? a->c_r1 : 0.f; p.c_r2 = a->r2 ? a->c_r2 : 0.f;
-    p.x_lo = (const int8_t*)a->x_lo; p.ln_gamma = (const f16*)a->ln_gamma; p.ln_beta = (const f16*)a->ln_beta;
-    p.addvec = (const f16*)a->addvec; p.add_rpg = a->add_rows_per_group >= 1 ? a->add_rows_per_group : 1; p.ln_eps = a->ln_eps;
     const int ncu = ew_cu_budget();                 // 256 unless the caller runs on a CU-masked stream
     const int grid = p.n_tiles < ncu ? p.n_tiles : ncu;
-#ifdef FF_TRACE
-    p.trace = g_ff_trace;
-#else
-    p.trace = nullptr;
-#endif
-    static const int stagger_env = [] { const char* e = getenv("EW_FF_STAGGER"); return e ? atoi(e) : 1; }();
-    p.stagger = stagger_env;
-    const bool lo = a->r1_lo || a->r2_lo || a->out_lo || a->x_lo;
+    const bool lo = a->r1_lo || a->r2_lo || a->out_lo;
     const bool r2 = a->r2 != nullptr;
     hipStream_t s = (hipStream_t)stream;
-#define FF_LAUNCH(LO_, R2_, XLO_)                                                                                          \
-    do {                                                                                                                   \
-        static std::atomic<unsigned long long> mask{0};                                                                    \
-        if (ew_status st = ew_ensure_dynamic_lds((const void*)ff320_kernel<LO_, R2_, XLO_>, LDS_BYTES, mask)) return st;   \
-        hipLaunchKernelGGL((ff320_kernel<LO_, R2_, XLO_>), dim3(grid), dim3(64 * NWV), LDS_BYTES, s, p);                   \
+#define FF_LAUNCH(LO_, R2_)                                                                                          \
+    do {                                                                                                             \
+        static std::atomic<unsigned long long> mask{0};                                                              \
+        if (ew_status st = ew_ensure_dynamic_lds((const void*)ff320_kernel<LO_, R2_>, LDS_BYTES, mask)) return st;   \
+        hipLaunchKernelGGL((ff320_kernel<LO_, R2_>), dim3(grid), dim3(64 * NWV), LDS_BYTES, s, p);                   \
     } while (0)
-    const bool xlo = a->x_lo != nullptr;
-    if (a->ln_folded) {                      // folded LayerNorm: the two operand sets the U-Net uses (anything else runs on the superset)
-        if (r2) FF_LAUNCH(true, true, 2);
-        else FF_LAUNCH(true, false, 2);
-    }
-    else if (lo && r2 && xlo) FF_LAUNCH(true, true, 1);
-    else if (a->ln_gamma && !xlo) FF_LAUNCH(true, true, 3);          // ln_gamma prologue on a plain fp16 x: one superset variant
-    else if (lo && r2) FF_LAUNCH(true, true, 0);
-    else if (lo && xlo) FF_LAUNCH(true, false, 1);
-    else if (lo) FF_LAUNCH(true, false, 0);
-    else if (r2) FF_LAUNCH(false, true, 0);
-    else FF_LAUNCH(false, false, 0);
+    if (lo && r2) FF_LAUNCH(true, true);
+    else if (lo) FF_LAUNCH(true, false);
+    else if (r2) FF_LAUNCH(false, true);
+    else FF_LAUNCH(false, false);
 #undef FF_LAUNCH
     return ew_check_launch("ew_ff_geglu320_f16");
 }

@@ -21,11 +21,6 @@
 #include "gemm_common.h"
 #include <type_traits>
 
-#ifdef EW_G2_TRACE
-// Segment timing (tools/experiments/exp13): a separate build of this file with -DEW_G2_TRACE (never the shipped library).
-__device__ unsigned long long g2_trace[2][8][8];
-#define EW_TS(x) asm volatile("s_memtime %0" : "=s"(x))
-#endif
 
 extern char g_gemm_last_kernel[64];
 
@@ -191,16 +186,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
                 }
             }
             if constexpr (MODE != EW_A_DENSE) src = ((a_mask[i] >> st_tap) & 1) ? src : st_zp;
-#if !(defined(EW_G2_ABLATE) && (EW_G2_ABLATE & 4))
             glds16(src, st_buf + (wave + NW * i) * 1024);
-#else
-            asm volatile("" ::"v"(src));                                                                // ablation: no DMA
-#endif
         } else {
             const int j = k - GA;
-#if !(defined(EW_G2_ABLATE) && (EW_G2_ABLATE & 4))
             if (j < GB_FULL || has_tail) glds16(b_ptr[j] + st_koff, st_buf + A_BYTES + (wave + NW * j) * 1024);
-#endif
         }
     };
     auto stage = [&](char* buf) __attribute__((always_inline)) {       // whole K-tile at once (prologue, and the DMA deferred past an epilogue)
@@ -247,9 +236,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
 
     f16x8 af0[FM], bf0[FN], af1[FM], bf1[FN];
     auto read_frags = [&](const char* buf, int so, f16x8 (&af)[FM], f16x8 (&bf)[FN]) __attribute__((always_inline)) {
-#if defined(EW_G2_ABLATE) && (EW_G2_ABLATE & 2)
-        return;                                                                                         // ablation: no ds_reads
-#endif
 #pragma unroll
         for (int j = 0; j < FN; ++j) bf[j] = *(const f16x8*)(buf + b_off[j] + so);
 #pragma unroll
@@ -270,11 +256,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-#if defined(EW_G2_ABLATE) && (EW_G2_ABLATE & 1)
-                asm volatile("" ::"v"(af[i]), "v"(bf[j]));                                              // ablation: no MFMA
-#else
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // D[n][m]
-#endif
                 const int idx = i * FN + j;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
@@ -310,51 +292,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
     bool stores_behind = false;                      // a full-tile epilogue's stores are newer than the DMA waited next
     int s_cur = 0;                                   // ring slot of stream position v
     bool pend = false;                               // pieces [P0,NP) of the newest stage still to be issued
-#ifdef EW_G2_TRACE
-    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tA0 = 0, sg0 = 0, sg1 = 0, sg2 = 0, sg3 = 0, sg3e = 0, nte = 0;
-    bool prev_end = false;
-#endif
     for (int v = 0; v < V; ++v) {
-#ifdef EW_G2_TRACE
-        tA0 = tA;
-        EW_TS(tA);
-#endif
         const int s_nxt = s_cur == NSTAGE - 1 ? 0 : s_cur + 1;
         const char* cur = smem + s_cur * STAGE;
         const bool tile_end = cur_kt == nk - 1;
         // ---- half-step 0: MFMA on k[0,32), fetch fragments of k[32,64)
         EW_WAIT_LGKM0();   // af0/bf0 (read one half-step ago) have landed: free, and it lets the MFMAs below start
-#ifdef EW_G2_TRACE
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (v > 0) {
-            sg0 += tB - tA0; sg1 += tC - tB; sg2 += tD - tC;
-            if (prev_end) { sg3e += tA - tD; ++nte; } else sg3 += tA - tD;
-        }
-        prev_end = tile_end;
-#endif
                            // without waiting for the reads issued next (hipcc otherwise emits lgkmcnt(0) after them)
         read_frags(cur, so1, af1, bf1);
         __builtin_amdgcn_sched_barrier(0);   // keep the reads AHEAD of the MFMAs (hipcc otherwise sinks them to the end)
         mma_il(af0, bf0, pend, std::integral_constant<int, P0>{}, std::integral_constant<int, NP>{});
         pend = false;
-#ifdef EW_G2_TRACE
-        EW_TS(tB);
-#endif
         // ---- publish K-tile v+1.  Unconditional (also on the last position, where the fragments read from the ring are
         // stale and never used): a conditional here makes hipcc put a conservative lgkmcnt(0) at the join, in front of
         // the half-step-1 MFMAs, which would expose the LDS latency of the reads just issued.
         wait_landed(v + 2 < staged, stores_behind);
         stores_behind = false;
-#ifdef EW_G2_TRACE
-        EW_TS(tC);
-#endif
         EW_WAIT_LGKM0();
         EW_COMPILER_FENCE();
         __builtin_amdgcn_s_barrier();
         EW_COMPILER_FENCE();
-#ifdef EW_G2_TRACE
-        EW_TS(tD);
-#endif
         read_frags(smem + s_nxt * STAGE, so0, af0, bf0);
         const bool st_now = !tile_end && staged < V;                             // slot of v is free from here on
         if (st_now) {
@@ -374,7 +331,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
             ++cur_i;
             const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
             // every store instruction of this wave executes iff its whole wave tile is inside the matrix
-            stores_behind = (tm * BM + wm * WM + WM <= p.M) && (tn * BN + wn * WN + WN <= p.N) && !(p.dbg & 3);
+            stores_behind = (tm * BM + wm * WM + WM <= p.M) && (tn * BN + wn * WN + WN <= p.N);
             // Epilogue through a wave-private LDS patch living in the ring slot of the K-tile just consumed (free since
             // barrier(v); protected from the next DMA by the barrier at the end): accumulators (D[n][m] layout = 4
             // consecutive columns per lane) -> ds_write_b128 -> read back ROW-major, 8 columns per lane -> every global
@@ -463,14 +420,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
                                 o[e] = (f16)x;
                                 if constexpr (LO) s8[e] = ew_split_enc(x, o[e]);
                             }
-                            if (FULL ? is_live(it) : (is_live(it) && m < p.M && n + 8 <= p.N && !(p.dbg & 1))) {
+                            if (FULL ? is_live(it) : (is_live(it) && m < p.M && n + 8 <= p.N)) {
                                 *(f16x8*)(p.out + (size_t)m * p.ld_out + n) = o;
                                 if constexpr (LO) {
                                     if (p.out_lo)
                                         *(u32x2*)(p.out_lo + (size_t)m * p.ld_out + n) =
                                             (u32x2){ew_pack4(s8[0], s8[1], s8[2], s8[3]), ew_pack4(s8[4], s8[5], s8[6], s8[7])};
                                 }
-                            } else if (!FULL && is_live(it) && m < p.M && !(p.dbg & 1)) {
+                            } else if (!FULL && is_live(it) && m < p.M) {
 #pragma unroll
                                 for (int e = 0; e < 8; ++e)                     // ragged N edge (e.g. conv_out N=4)
                                     if (n + e < p.N) {
@@ -519,19 +476,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
                             const f32x4 lo = *(const f32x4*)(patch + row * LDO + c8), hi = *(const f32x4*)(patch + row * LDO + c8 + 4);
                             const f16x8 o = {(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
                             const int no = (n_w0 >> 1) + c8;
-                            if (FULL ? is_live(it) : (is_live(it) && m < p.M && 2 * no < p.N && !(p.dbg & 1)))
+                            if (FULL ? is_live(it) : (is_live(it) && m < p.M && 2 * no < p.N))
                                 *(f16x8*)(p.out + (size_t)m * p.ld_out + no) = o;
                         }
                         __builtin_amdgcn_wave_barrier();
                     }
                 }
             };
-            if (p.dbg & 2) {
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) { asm volatile("" :: "v"(acc[i][j])); acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-            } else {
+            {
                 if (stores_behind) epilogue(std::true_type{}); else epilogue(std::false_type{});
                 // the patch lives in the ring slot the NEXT DMA (stage at the top of the next position) will overwrite
                 EW_WAIT_LGKM0();
@@ -542,12 +494,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 && 
             if (staged < V) { stage(smem + s_prev * STAGE); ++staged; }   // the DMA deferred at this tile's last barrier
         }
     }
-#ifdef EW_G2_TRACE
-    if ((blockIdx.x == 0 || blockIdx.x == 131) && lane == 0) {
-        unsigned long long* o = g2_trace[blockIdx.x == 0 ? 0 : 1][wave & 7];
-        o[0] = sg0; o[1] = sg1; o[2] = sg2; o[3] = sg3; o[4] = sg3e; o[5] = nte; o[6] = (unsigned long long)V; o[7] = (unsigned long long)nk;
-    }
-#endif
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int MODE, int EPI>
@@ -615,11 +561,6 @@ ew_status dispatch_epi(const GemmP& p, hipStream_t s) {
 
 }  // namespace
 
-#ifdef EW_G2_TRACE
-extern "C" int ew_debug_trace_read(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g2_trace), sizeof(g2_trace));
-}
-#endif
 
 ew_status ew_gemm2_dispatch(const GemmP& p, hipStream_t s) {
     if (p.mode == EW_A_CONV3X3) return dispatch_epi<EW_A_CONV3X3>(p, s);

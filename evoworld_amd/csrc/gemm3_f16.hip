@@ -26,11 +26,7 @@ namespace {
 #define EW3_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 #define EW3_FENCE() asm volatile("" ::: "memory")
 #define EW3_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#if defined(EW_G3_ABLATE) && (EW_G3_ABLATE & 2)
-#define EW3_LDS(ptr) (f16x8{})                       /* ablation: no ds_reads */
-#else
 #define EW3_LDS(ptr) (*(const f16x8*)(ptr))
-#endif
 
 // The file is compiled twice (Makefile): EW3_BN = 320 (every channel count of the U-Net) and EW3_BN = 256 (gemm3b_f16.o: the VAE's
 // 256- / 512-channel convs, which otherwise run on generation 2's 128x256 tile at about a third of this kernel's rate).
@@ -51,33 +47,13 @@ static_assert(BN % 64 == 0 && FN % 2 == 0 && (FM * FN) % 8 == 0, "tile geometry"
 constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
 constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW, NP = GA + GB;        // 4 + 5 DMA pieces per wave per K-tile
 constexpr int NSTEP = 2 * FN;                                          // 20 steps (k-half, W fragment) per K-tile
-#ifdef EW_G3_NOPIN
-#define EW3_PIN()
-#else
 #define EW3_PIN() __builtin_amdgcn_sched_barrier(0)
-#endif
-#ifndef EW_G3_DIST
-#define EW_G3_DIST 2
-#endif
 constexpr int ITEMS_BYTES = 8192;                                      // work-item table: up to 512 (tile, k0, k1) entries per block
-constexpr int PD = EW_G3_DIST;                                         // W fragments are read PD steps ahead of their MFMAs (ring of 4)
+constexpr int PD = 2;                                         // W fragments are read PD steps ahead of their MFMAs (ring of 4)
 constexpr int BAR_STEP = NSTEP - 1 - PD;                               // barrier after the step that issues the tile's last read
 
-// ---- halo-slab A loader of the stride-1 3x3 convs (round 5; MODE == EW_A_CONV3X3H, chosen by the dispatcher, not part of the ABI) ----
-// The plain conv mode stages one 256-row x 64-channel A tile per (channel chunk, tap): 9 x 32 KB per chunk, every tap re-fetching the same
-// input lines through L2 (measured: 99 GB of L2-miss traffic per forward for ~10 GB of unique conv operands).  For a tile of 256 consecutive
-// output pixels = 256 / W whole image rows (W = 64 / 128 / 256) the three taps of one kernel ROW (ky) read the same pixels shifted by -1 / 0 / +1:
-// they are served from ONE slab = the tile's image rows with a zero pixel before and after each row (W + 2 slab rows per image row, the
-// left / right padding of the conv), staged once per (chunk, ky) = 33 KB instead of 3 x 32 KB.  Tap kx of output row r (image row q = r / W
-// of the tile) reads slab row r + 2 q + kx: a pure address shift of the A fragment reads, no per-read masking; rows above / below the image
-// (ky) are zero-page rows at staging time, exactly as in the plain mode.  K order, operand values and the MFMA sequence are unchanged:
-// results are bit-identical to the plain mode's.  LDS: two slabs (by kernel-row group) + two W stages (by K-tile) + the item table = 154 KB.
-constexpr int EW_A_CONV3X3H = 3;
-constexpr int SLAB_P = BM / 8 + 1;                                     // 33 one-KB pieces = 264 slab rows >= 256 + 2 * (256 / W) for W >= 64
-constexpr int SLAB_BYTES = SLAB_P * 1024;
-constexpr int GAH = (SLAB_P + NW - 1) / NW;                            // 5 slab pieces per wave (the fifth on wave 0 only)
-constexpr int W_BYTES = BN * 128;                                      // one K-tile of W
-constexpr int HALO_LDS = 2 * SLAB_BYTES + 2 * W_BYTES;                 // (+ ITEMS_BYTES)
+// (Round 5's halo-slab A loader for the stride-1 3x3 convs -- one slab per (channel chunk, kernel row) serving the three kernel columns as address
+// shifts, bit-identical, measured +-0 in time and in FETCH_SIZE, profiles/r05_f_halo_slab_* -- was removed from the source in round 6: commit e42126f.)
 
 // Tile id -> (tm, tn).  Ids are consumed in XCD-contiguous chunks of 32 (one per CU of an XCD at a time), so 32 consecutive ids
 // should form a 2-D block that shares as many operand rows as possible in that XCD's 4 MB L2.  With more than BAND tile
@@ -103,35 +79,19 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     // epilogue family: GEGLU (EPI & 8) and the conv modes without lo8 operands go through a wave-private LDS patch; dense GEMMs
     // and everything that carries the split residual stream use the LDS-free direct epilogue (permuted W staging)
     constexpr bool DIRECT = (EPI & 8) == 0 && (MODE == EW_A_DENSE || (EPI & 16));
-#ifndef EW_G3_BIAS_INIT
-#define EW_G3_BIAS_INIT 1       /* 1 (round 4): the bias vector is the accumulators' initial value (10 8-byte loads + 40 cvt per work item) instead of
-                                   one cvt + add per output element in every epilogue step */
-#endif
-#ifndef EW_G3_RB_INIT
-#define EW_G3_RB_INIT 1         /* round 5: in the DIRECT variants the row-bias (one vector per row group) enters through the accumulators' INITIAL
-                                   value, next to the bias (init_acc: 40 8-byte loads of L2-resident rows per work item) -- the epilogue steps lose a
-                                   16-byte operand load, 16 VALU and the per-step row-group computation (an integer division) */
-#endif
 #ifndef EW_G3_RESLDS
 #define EW_G3_RESLDS 1          /* round 5: residual operands of the DIRECT epilogue come in through the LDS (see the RES_LDS epilogue below) */
 #endif
-    constexpr bool HALO = MODE == EW_A_CONV3X3H;
-    static_assert(!HALO || (EPI & ~16) == 1, "halo-slab loader: built for the row-bias / split-output epilogue (conv1 of the resblocks) only");
-    constexpr bool RB_INIT = bool(EW_G3_RB_INIT) && bool(EW_G3_BIAS_INIT) && DIRECT && (EPI & 1);
+    constexpr bool RB_INIT = DIRECT && (EPI & 1);
     // DIRECT variants with residual operands: the epilogue takes both LDS stages as landing zones of its residual tiles (LDS-DMA, 8 KB per
     // wave, operand and row fragment: 60-120 KB in flight per CU instead of the ~24 KB two VGPR operand sets allowed), so the first
     // K-tile of the NEXT work item is not prefetched during the last K-tile of this one but staged inside the epilogue.
-    constexpr bool RES_LDS = bool(EW_G3_RESLDS) && bool(EW_G3_RB_INIT) && bool(EW_G3_BIAS_INIT) && DIRECT && (EPI & 6) != 0;
+    constexpr bool RES_LDS = bool(EW_G3_RESLDS) && DIRECT && (EPI & 6) != 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
-#ifndef EW_PRIO_YOUNG
-#define EW_PRIO_YOUNG 1       /* A/B (round 4: -0.3 ... -0.7 ms per forward each, profiles/r04_l_static_prio.txt): static s_setprio 1 for the second-dispatched half of the workgroup */
-#endif
-#if EW_PRIO_YOUNG
     if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
 
     // ---- tile sequence of this persistent block: step i -> tile id i*G + (b%8)*(G/8) + b/8  (XCD-contiguous chunks)
     const int G = gridDim.x;
@@ -159,9 +119,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     // The items (tile id, first K-tile, end K-tile) go into a small LDS table behind the two stages: the loader and the MFMA
     // stream each read one entry per tile.  (Computing them in place -- a branchy expression inside the loader lambda -- kept
     // hipcc from promoting the lambdas' captured state to registers: 600 bytes of scratch per lane.)
-    int* const items = (int*)(smem + (HALO ? HALO_LDS : 2 * STAGE));
-    // W stage s of the halo layout, as a base the stage-relative offsets (b_rd: A_BYTES + ...) can be added to
-    auto stage_base = [&](int st) __attribute__((always_inline)) -> char* { return HALO ? smem + (2 * SLAB_BYTES - A_BYTES) + st * W_BYTES : smem + st * STAGE; };
+    int* const items = (int*)(smem + 2 * STAGE);
+    auto stage_base = [&](int st) __attribute__((always_inline)) -> char* { return smem + st * STAGE; };
     for (int w = threadIdx.x; w < n_sk + n_dp; w += 64 * NW) {
         int id, k0 = 0, k1 = nk;
         if (w < n_sk) {
@@ -187,13 +146,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     const int slot = (lane & 7) ^ srow;
 
     // ---------------- loader state (one K-tile ahead of the MFMA stream, across output tiles) ----------------
-    constexpr int NTAP = (MODE == EW_A_CONV3X3 || HALO) ? 9 : (MODE == EW_A_CONVT3 ? 3 : 1);
-    constexpr int GAX = HALO ? GAH : GA;   // A-side DMA pieces per wave and staging
-    constexpr int NPX = GAX + GB;
+    constexpr int NTAP = MODE == EW_A_CONV3X3 ? 9 : (MODE == EW_A_CONVT3 ? 3 : 1);
     int ld_w = 0, ld_kt = 0, ld_k1 = 0, ld_tap = 0, ld_cc = 0;   // ld_kt == ld_k1: the next stage_begin opens work item ld_w
-    int a_ctr[GAX];                        // centre-tap pixel (row) index in the source tensors (HALO: (pixel of the slab row << 3) | kernel-row validity bits)
-    int a_mask[HALO ? 1 : GA];             // bits 0..8 tap validity, bits 16..27 upsample (dy,dx) codes
-    int ld_sb = 0;                         // HALO: slab buffer of the kernel-row group staged last
+    int a_ctr[GA];                         // centre-tap pixel (row) index in the source tensors
+    int a_mask[GA];                        // bits 0..8 tap validity, bits 16..27 upsample (dy,dx) codes
     const f16* b_ptr0 = p.w;               // W row of this lane's first piece (+ its 16-byte slot); piece j adds j*NW*8 rows
 
     auto loader_new_tile = [&](const int id) __attribute__((always_inline)) {
@@ -205,24 +161,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));
         const int srow_o = lane_o >> 3, slot_o = (lane_o & 7) ^ srow_o;
-        if constexpr (HALO) {
-            // slab row s = (wave + 8 i) * 8 + srow  ->  image row q = s / (W + 2) of the tile, slab column xs = s % (W + 2): columns 0 and W + 1 are
-            // the zero pixels beside the row, column xs the pixel m0 + q W + xs - 1
-            const int wp = p.w_in + 2, nq = BM / p.w_in;
 #pragma unroll
-            for (int i = 0; i < GAH; ++i) {
-                const int sr = (wave + NW * i) * 8 + srow_o;
-                const int q = sr / wp, xs = sr - q * wp;
-                int b = m0 + q * p.w_in + xs - 1;
-                const bool ok = q < nq && xs >= 1 && xs <= p.w_in && b < p.M;
-                b = ok ? b : 0;
-                const int yb = (b / p.w_in) % p.h_in;
-                const int mk = ok ? ((yb >= 1 ? 1 : 0) | 2 | (yb + 1 < p.h_in ? 4 : 0)) : 0;      // kernel rows ky = 0 / 1 / 2 stay inside the image
-                a_ctr[i] = (b << 3) | mk;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < (HALO ? 0 : GA); ++i) {
+        for (int i = 0; i < GA; ++i) {
             int m = m0 + (wave + NW * i) * 8 + srow_o;
             m = m < p.M ? m : p.M - 1;
             int ctr, mask = 1, dcode = 0;
@@ -278,9 +218,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     int st_tap = 0, st_ld = 0, st_ch = 0;
     size_t st_koff = 0;
     char* st_buf = smem;
-    char* st_sbuf = smem;                  // HALO: slab buffer being staged
-    bool st_slab = false;                  // HALO: this staging opens a kernel-row group (first K-tile of a work item, or kx == 0): the slab goes with it
-    int st_ky = 0;
     auto stage_begin = [&](char* buf) __attribute__((always_inline)) {
         bool opened = false;
         if (ld_kt == ld_k1) {
@@ -304,12 +241,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
         int dpix = 0;                                                       // wave-uniform tap delta in pixels
         if constexpr (MODE == EW_A_CONV3X3) dpix = (st_tap / 3 - 1) * p.w_in + (st_tap % 3 - 1);
         else if constexpr (MODE == EW_A_CONVT3) dpix = (st_tap - 1) * p.tP;
-        else if constexpr (HALO) {
-            st_ky = st_tap / 3;
-            st_slab = opened || st_tap == st_ky * 3;
-            if (st_slab) { ld_sb ^= 1; st_sbuf = smem + ld_sb * SLAB_BYTES; }
-            dpix = (st_ky - 1) * p.w_in;
-        }
         st_dl = (long long)dpix * st_ld + st_ch;
         st_koff = (size_t)ld_kt * BK;
         // K order: channel-chunk major, tap minor (the taps of a 64-channel chunk re-hit the same lines in L2 / TCP)
@@ -317,20 +248,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
         ++ld_kt;
     };
     auto stage_piece = [&](int k) __attribute__((always_inline)) {     // k is a compile-time constant after unrolling
-        if constexpr (HALO) {
-            if (k < GAH) {
-                if (st_slab && (k < GAH - 1 || wave + NW * k < SLAB_P)) {
-                    const int c = a_ctr[k];
-                    const f16* src = st_base + ((long long)(c >> 3) * st_ld + (st_dl + slot * 8));
-                    src = ((c >> st_ky) & 1) ? src : st_zp;
-                    glds16(src, st_sbuf + (wave + NW * k) * 1024);
-                }
-            } else {
-                const int j = k - GAH;
-                glds16(b_ptr0 + (size_t)(j * NW * 8) * p.K + st_koff, st_buf + A_BYTES + (wave + NW * j) * 1024);
-            }
-            return;
-        }
         if (k < GA) {
             const int i = k;
             const f16* src = st_base + ((long long)a_ctr[i] * st_ld + (st_dl + slot * 8));
@@ -342,16 +259,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                 }
             }
             if constexpr (MODE != EW_A_DENSE) src = ((a_mask[i] >> st_tap) & 1) ? src : st_zp;
-#if defined(EW_G3_ABLATE) && (EW_G3_ABLATE & 4)
-            asm volatile("" ::"v"(src));                                                                         // ablation: no DMA
-#else
             glds16(src, st_buf + (wave + NW * i) * 1024);
-#endif
         } else {
             const int j = k - GA;
-#if !(defined(EW_G3_ABLATE) && (EW_G3_ABLATE & 4))
             glds16(b_ptr0 + (size_t)(j * NW * 8) * p.K + st_koff, st_buf + A_BYTES + (wave + NW * j) * 1024);
-#endif
         }
     };
 
@@ -365,22 +276,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
         b_rd[kh] = A_BYTES + (wn * WN + frow) * 128 + so;
     }
 
-    // HALO: the A fragment of row fragment i, k-half kh and kernel column kx sits at slab row wm*64 + i*16 + frow + 2 q + kx (q = image row of the
-    // wave's 64 rows inside the tile: W >= 64), 16-byte slot ((kh*4 + fks) ^ (row & 7)); recomputed per K-tile from the thread id (kx changes with
-    // every K-tile; nothing lane-constant is kept live across the stream)
-    int cur_tap = 0, cur_sb = 0;           // consumer side: tap (ky*3 + kx) and slab buffer of the K-tile at stream position v
-    auto halo_ard = [&](const int kx, const int kh) __attribute__((always_inline)) {
-        int lane_o = tid & 63;
-        asm volatile("" : "+v"(lane_o));
-        const int rr = (lane_o & 15) + kx + 2 * ((wm * WM) / p.w_in);
-        return (wm * WM + rr) * 128 + (((kh * 4 + (lane_o >> 4)) ^ (rr & 7)) << 4);
-    };
-
     f32x4 acc[FM][FN];
     // Accumulators of a work item start as the bias of its tile column (every row fragment the same 4 columns per lane and
     // fragment), or as zeros for the TAIL of a stream-K tile (k0 > 0: another block owns the head, and the bias with it).
     auto init_acc = [&](const int id, const int k0) __attribute__((always_inline)) {
-#if EW_G3_BIAS_INIT
         int tm, tn;
         tile_coords(id, p.tiles_m, p.tiles_n, p.band, tm, tn);
         int lane_o = tid & 63;                       // opaque copy: keeps the bias addresses out of the main loop's live set
@@ -414,12 +313,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                 }
             }
         }
-#else
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#endif
     };
     f16x8 af[2][FM];                       // A fragments of the two k-halves
     f16x8 bfr[4];                          // W fragment ring: step t consumes bfr[t & 3]
@@ -427,7 +320,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     // ---------------- prologue ----------------
     stage_begin(stage_base(0));
 #pragma unroll
-    for (int k = 0; k < NPX; ++k) stage_piece(k);
+    for (int k = 0; k < NP; ++k) stage_piece(k);
     int staged = 1;
     EW3_WAIT_VM0();
     EW3_FENCE();
@@ -436,13 +329,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     int cur_w = 0, cur_id, cur_kt, cur_k1;
     EW3_GET_ITEM(0, cur_id, cur_kt, cur_k1);
     cur_w = 1;
-    if constexpr (HALO) {
-        cur_tap = cur_kt - (cur_kt / NTAP) * NTAP;
-        cur_sb = 1;                                    // the loader's first slab went to buffer 1
-        const int a0 = halo_ard(cur_tap - (cur_tap / 3) * 3, 0);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af[0][i] = EW3_LDS(smem + SLAB_BYTES + a0 + i * 2048);
-    } else {
+    {
 #pragma unroll
         for (int i = 0; i < FM; ++i) af[0][i] = EW3_LDS(smem + a_rd[0] + i * 2048);
     }
@@ -456,18 +343,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
         const char* cur = stage_base(s_cur);
         char* nxt = stage_base(s_cur ^ 1);
         const bool tile_end = cur_kt == cur_k1 - 1;
-        // HALO: where this K-tile's second-half A fragments and the next K-tile's first-half ones sit
-        const char* slab_c = smem + cur_sb * SLAB_BYTES;
-        const char* slab_n = slab_c;
-        int nxt_tap = cur_tap + 1, nxt_sb = cur_sb, a1c = 0, a0n = 0;
-        if constexpr (HALO) {
-            a1c = halo_ard(cur_tap - (cur_tap / 3) * 3, 1);
-            if (nxt_tap == NTAP) nxt_tap = 0;
-            const int nkx = nxt_tap - (nxt_tap / 3) * 3;
-            if (nkx == 0) nxt_sb ^= 1;                 // the next K-tile opens a kernel-row group: its slab is in the other buffer
-            slab_n = smem + nxt_sb * SLAB_BYTES;
-            a0n = halo_ard(nkx, 0);
-        }
         const bool pend = staged < V;                // K-tile v+1 exists: stage it into the other slot during steps 0..8
         // RES_LDS: at a tile end both stages belong to the epilogue's residual tiles; K-tile v+1 (the first of the next work item)
         // is staged inside the epilogue instead (tile-end section below)
@@ -481,7 +356,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                 const int kh2 = (t + PD) / FN, j2 = (t + PD) - kh2 * FN;
                 bfr[(t + PD) & 3] = EW3_LDS(cur + b_rd[kh2] + j2 * 2048);
             }
-            if (t < FM) af[1][t] = HALO ? EW3_LDS(slab_c + a1c + t * 2048) : EW3_LDS(cur + a_rd[1] + t * 2048);
+            if (t < FM) af[1][t] = EW3_LDS(cur + a_rd[1] + t * 2048);
             if (t >= NSTEP - PD) {
                 // first fragments of the next K-tile -- except at a tile end: the epilogue needs the registers (160 live
                 // accumulators), so they are read after it instead
@@ -489,22 +364,18 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                     bfr[(t + PD) & 3] = EW3_LDS(nxt + b_rd[0] + (t + PD - NSTEP) * 2048);
                     if (t >= NSTEP - 2) {
                         const int i0 = (t - (NSTEP - 2)) * 2;
-                        af[0][i0] = HALO ? EW3_LDS(slab_n + a0n + i0 * 2048) : EW3_LDS(nxt + a_rd[0] + i0 * 2048);
-                        af[0][i0 + 1] = HALO ? EW3_LDS(slab_n + a0n + (i0 + 1) * 2048) : EW3_LDS(nxt + a_rd[0] + (i0 + 1) * 2048);
+                        af[0][i0] = EW3_LDS(nxt + a_rd[0] + i0 * 2048);
+                        af[0][i0 + 1] = EW3_LDS(nxt + a_rd[0] + (i0 + 1) * 2048);
                     }
                 }
             }
-            if (t < NPX) {
+            if (t < NP) {
                 if (pend_now) stage_piece(t);
             }
             EW3_PIN();
 #pragma unroll
             for (int i = 0; i < FM; ++i)
-#if defined(EW_G3_ABLATE) && (EW_G3_ABLATE & 1)
-                asm volatile("" ::"v"(bfr[t & 3]), "v"(af[kh][i]));                                              // ablation: no MFMA
-#else
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[t & 3], af[kh][i], acc[i][j], 0, 0, 0);   // D[n][m]
-#endif
             EW3_PIN();
             if (t == BAR_STEP) {
                 // every fragment read of K-tile v has been issued; publish K-tile v+1 and free this slot.  Unconditional
@@ -517,8 +388,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
             }
         }
         s_cur ^= 1;
-        const int old_sb = cur_sb;
-        if constexpr (HALO) { cur_tap = nxt_tap; cur_sb = nxt_sb; }        // (overridden below at a work-item end)
         if (++cur_kt == cur_k1) {
             // ------------------------- end of work item: epilogue of output tile cur_id (or stream-K hand-over) -------------------------
             const int id = cur_id;
@@ -527,11 +396,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
             if (cur_w < n_sk + n_dp) {
                 EW3_GET_ITEM(cur_w, cur_id, cur_kt, cur_k1);
                 cur_tail = cur_kt > 0;                       // never true past item 0; kept general
-            }
-            if constexpr (HALO) {
-                // a work item always opens with its own slab (the loader flipped buffers for it, whatever the tap it starts at)
-                cur_sb = old_sb ^ 1;
-                cur_tap = cur_kt - (cur_kt / NTAP) * NTAP;
             }
             ++cur_w;
             int tm, tn;
@@ -581,12 +445,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                             for (int jj = 0; jj < CP / 16; ++jj) {
                                 const int j = h * (CP / 16) + jj;
                                 const int n = n_w0 + j * 16 + fks * 4;
-#if EW_G3_BIAS_INIT
                                 f32x4 x = acc[i][j];
-#else
-                                const f16x4 b4 = *(const f16x4*)((const char*)bp + (unsigned)(n * mbias) * 2u);
-                                f32x4 x = acc[i][j] + (f32x4){(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
-#endif
                                 if constexpr (RB) {
                                     const f16x4 r4 = *(const f16x4*)((const char*)rbp + (unsigned)(g * ldrb + n * mrb) * 2u);
                                     x += (f32x4){(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
@@ -609,7 +468,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                                 const int row = is_live(it) ? idx / VPR : 0, c8 = is_live(it) ? (idx - row * VPR) * 8 : 0;
                                 const int m = m_w0 + i * 16 + row, n = n_w0 + h * CP + c8;
                                 const f16x8 o = *(const f16x8*)(patch16 + row * LDH + c8);
-                                if (is_live(it) && (FULL || m < p.M) && !(p.dbg & 1)) *(f16x8*)((char*)p.out + (unsigned)(m * p.ld_out + n) * 2u) = o;
+                                if (is_live(it) && (FULL || m < p.M)) *(f16x8*)((char*)p.out + (unsigned)(m * p.ld_out + n) * 2u) = o;
                             }
                             __builtin_amdgcn_wave_barrier();
                         }
@@ -639,9 +498,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                         const int m = m_w0 + i * 16 + rowv[it], n = n_w0 + h * CP + c8v[it];
                         const int mc = FULL ? m : min(m, p.M - 1);
                         // uniform base + 32-bit byte offset (every operand of this path is < 4 GB): one VGPR per address
-#if !EW_G3_BIAS_INIT
-                        bvv = *(const f16x8*)((const char*)bp + (unsigned)(n * mbias) * 2u);
-#endif
                         if constexpr (RB) {
                             const int g = rpg >= WM ? g0 + (mc >= gbound ? 1 : 0) : mc / rpg;
                             rbv = *(const f16x8*)((const char*)rbp + (unsigned)(g * ldrb + n * mrb) * 2u);
@@ -669,9 +525,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                                 f16x8 o;
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) {
-#if !EW_G3_BIAS_INIT
-                                    vv[e] += (float)bvv[e];
-#endif
                                     if constexpr (RB) vv[e] += (float)rbv[e];
                                 }
                                 // (no activation in this path: SiLU / GELU problems with residual operands or conv modes run on generation 2)
@@ -687,7 +540,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                                 else if (h + 1 < NH) fetch(i, h + 1, 0);
                                 else if (i + 1 < FM) fetch(i + 1, 0, 0);
                                 __builtin_amdgcn_sched_barrier(0);
-                                if (is_live(it) && (FULL || m < p.M) && !(p.dbg & 1)) *(f16x8*)((char*)p.out + (unsigned)(m * p.ld_out + n) * 2u) = o;
+                                if (is_live(it) && (FULL || m < p.M)) *(f16x8*)((char*)p.out + (unsigned)(m * p.ld_out + n) * 2u) = o;
                             }
                             __builtin_amdgcn_wave_barrier();
                         }
@@ -705,17 +558,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                     constexpr int NQ = FN / 2;                  // 5 fragment pairs = 5 x 32 columns per wave tile
                     // vmcnt is in-order: a load issued after a store cannot be waited for without draining that store, so the
                     // operands of step s+1 are requested BEFORE the store of step s -- but after step s has consumed its own.
-#ifndef EW_G3_EPI_DEPTH
-#define EW_G3_EPI_DEPTH 2       /* epilogue steps whose operand loads are in flight (operand register sets).  Round 4 A/B (profiles/r04_o_epilogue_depth.txt):
-                                   2 buys 2-7 % on the short-K residual GEMMs now that the bias / activation code is out of the steps (it only spilled in
-                                   round 2); 3 spills in the conv + row-bias variants (+10 %); <0,23> (two split residuals) loses at 2 already */
-#endif
-                    constexpr int ED = (EPI == 23) ? 1 : ((R1 || R2 || RB) ? EW_G3_EPI_DEPTH : 1);
+                    constexpr int ED = (EPI == 23) ? 1 : ((R1 || R2 || RB) ? 2 : 1);
                     f16x8 rbv[ED], q1v[ED], q2v[ED];
                     u32x2 q1l[ED], q2l[ED];
-#if !EW_G3_BIAS_INIT
-                    f16x8 bvv;
-#endif
                     const int rpg = p.rows_per_group;
                     const int g0 = min(m_w0, p.M - 1) / rpg;             // wave tiles past the last row must not index a group beyond the last
                     const int gbound = rpg >= WM ? (g0 + 1) * rpg : 0x7fffffff;
@@ -725,9 +570,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                         const int m = m_w0 + i * 16 + frow, n = ncol0 + q * 32;
                         const int mc = FULL ? m : min(m, p.M - 1);
                         // uniform base + 32-bit byte offset (every operand of this path is < 4 GB): one VGPR per address
-#if !EW_G3_BIAS_INIT
-                        bvv = *(const f16x8*)((const char*)bp + (unsigned)(n * mbias) * 2u);
-#endif
                         if constexpr (RB) {
                             const int g = rpg >= WM ? g0 + (mc >= gbound ? 1 : 0) : mc / rpg;
                             rbv[st] = *(const f16x8*)((const char*)rbp + (unsigned)(g * ldrb + n * mrb) * 2u);
@@ -755,9 +597,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                             int s8[8];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {
-#if !EW_G3_BIAS_INIT
-                                vv[e] += (float)bvv[e];
-#endif
                                 if constexpr (RB) vv[e] += (float)rbv[st][e];
                             }
                             if (silu) {
@@ -781,7 +620,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                             __builtin_amdgcn_sched_barrier(0);
                             if (k + ED < FM * NQ) fetch(k + ED);
                             __builtin_amdgcn_sched_barrier(0);
-                            if ((FULL || m < p.M) && !(p.dbg & 1)) {
+                            if ((FULL || m < p.M)) {
                                 *(f16x8*)((char*)p.out + (unsigned)(m * p.ld_out + n) * 2u) = o;
                                 if constexpr (LO) {
                                     if (p.out_lo) *(u32x2*)((char*)p.out_lo + (unsigned)(m * p.ld_out + n)) = ol;
@@ -795,25 +634,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                     f32x4 bq[FN];
 #pragma unroll
                     for (int j = 0; j < FN; ++j) {
-#if EW_G3_BIAS_INIT
                         bq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#else
-                        const f16x4 b4 = *(const f16x4*)(bp + (n_w0 + j * 16 + fks * 4) * mbias);
-                        bq[j] = (f32x4){(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
-#endif
                     }
 #pragma unroll
                     for (int i = 0; i < FM; ++i) {
 #pragma unroll
                         for (int q = 0; q < FN / 2; ++q) {
                             const f32x4 va = acc[i][2 * q] + bq[2 * q], gg = acc[i][2 * q + 1] + bq[2 * q + 1];
-#ifdef EW_G3_NOGELU
-                            const f32x2 o01 = (f32x2){va[0], va[1]} * (f32x2){gg[0], gg[1]};        // measurement only: GELU cost
-                            const f32x2 o23 = (f32x2){va[2], va[3]} * (f32x2){gg[2], gg[3]};
-#else
                             const f32x2 o01 = ew_vgelu2((f32x2){va[0], va[1]}, (f32x2){gg[0], gg[1]});
                             const f32x2 o23 = ew_vgelu2((f32x2){va[2], va[3]}, (f32x2){gg[2], gg[3]});
-#endif
                             const f16x4 o4 = {(f16)o01[0], (f16)o01[1], (f16)o23[0], (f16)o23[1]};
                             *(f16x4*)((f16*)patch + frow * (CP + 8) + q * 16 + fks * 4) = o4;      // fp16 patch, row stride 176 B
                         }
@@ -827,13 +656,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                             const int no = (n_w0 >> 1) + c8;
                             // non-temporal: the 4C-wide GEGLU output (1.2 GB at level 0) only evicts the operands from L2
                             // (+5..6 % measured here; the same hint on the other epilogues measured -1..-18 %)
-                            if (is_live(it) && (FULL || m < p.M) && !(p.dbg & 1)) __builtin_nontemporal_store(o, (f16x8*)(p.out + (size_t)m * p.ld_out + no));
+                            if (is_live(it) && (FULL || m < p.M)) __builtin_nontemporal_store(o, (f16x8*)(p.out + (size_t)m * p.ld_out + no));
                         }
                         __builtin_amdgcn_wave_barrier();
                     }
                 }
             };
-            bool res_run = false;                    // RES_LDS: run the epilogue below (not a stream-K contributor / dbg bit 1)
+            bool res_run = false;                    // RES_LDS: run the epilogue below (not a stream-K contributor)
             if (sk_finish) {
                 // stream-K finisher: block seq0+1 wrote its partial of this tile as the first thing it did
                 if (tid == 0) {
@@ -861,9 +690,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                 int lane_o = tid & 63;
                 asm volatile("" : "+v"(lane_o));
                 const f32x4* wsp = (const f32x4*)sk.ws + (size_t)(seq0 + 1) * (FM * FN * 64 * NW) + wave * 64 + lane_o;
-                // (HALO: the released W stage holds 40 KB: four pieces per wave and round instead of eight)
-                constexpr int SKU = HALO ? 4 : 8;
-                char* const stg = stage_base(s_cur ^ 1) + (HALO ? A_BYTES : 0) + wave * (SKU * 1024);
+                constexpr int SKU = 8;
+                char* const stg = stage_base(s_cur ^ 1) + wave * (SKU * 1024);
 #pragma unroll
                 for (int b0 = 0; b0 < FM * FN; b0 += SKU) {
 #pragma unroll
@@ -882,12 +710,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                 __builtin_amdgcn_s_barrier();
                 EW3_FENCE();
             }
-            if (p.dbg & 2) {
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(acc[i][j]));
-            } else if (sk_contribute) {
+            if (sk_contribute) {
                 // stream-K contributor: accumulators -> slot seq0 of the uncached workspace in [fragment][thread] order (16 B per
                 // lane, 1 KB per wave instruction), then publish.  Every thread drains its own stores (vmcnt counts stores on
                 // gfx9) before the barrier; one thread raises the flag after it.
@@ -940,7 +763,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                 char* const stage_next = smem + s_cur * STAGE;            // stage of stream position v+1 (free since the barrier of position v-1)
                 char* const stage_done = smem + (s_cur ^ 1) * STAGE;      // stage just consumed (free since this position's barrier)
                 const bool deferred = pend;                               // K-tile v+1 exists and has not been staged yet
-                const bool exact = full && !(p.dbg & 1) && (!LO || p.out_lo);       // every store instruction of a fragment is issued
+                const bool exact = full && (!LO || p.out_lo);       // every store instruction of a fragment is issued
 #define EW3_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
                 auto res_phase = [&](auto phase_tag) __attribute__((always_inline)) {
                     constexpr int PH = decltype(phase_tag)::value;        // 0: fragments 0 .. FM-2 (one residual) or all (two), 1: fragment FM-1 (one residual)
@@ -997,7 +820,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
                             }
                         }
                         const int m = m_w0 + i * 16 + frow;
-                        const bool live = (m < p.M) && !(p.dbg & 1);
+                        const bool live = (m < p.M);
                         const unsigned ob = (unsigned)(m * p.ld_out + n_w0 + fks * 8);
                         const float ca = p.c_acc, cA = (NOPD == 2 || R1) ? p.c_r1 : p.c_r2, cB = p.c_r2;
 #pragma unroll
@@ -1087,12 +910,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
             // first fragments of the next tile's first K-tile (skipped at steps 18-19 of this position)
             {
                 const char* c2 = stage_base(s_cur);
-                if constexpr (HALO) {
-                    const char* sl = smem + cur_sb * SLAB_BYTES;
-                    const int a0 = halo_ard(cur_tap - (cur_tap / 3) * 3, 0);
-#pragma unroll
-                    for (int i = 0; i < FM; ++i) af[0][i] = EW3_LDS(sl + a0 + i * 2048);
-                } else {
+                {
 #pragma unroll
                     for (int i = 0; i < FM; ++i) af[0][i] = EW3_LDS(c2 + a_rd[0] + i * 2048);
                 }
@@ -1165,6 +983,7 @@ int ew_gemm3_sk_init_b256(hipStream_t s) { return sk_workspace(s, true) != nullp
 int ew_gemm3_sk_status_b256() {
     int bad = 0;
 #endif
+    std::lock_guard<std::mutex> lock(sk_mutex);      // the descriptor ring is written under the same mutex by launching threads
     for (int i = 0; i < SK_POOL; ++i) {
         SkWorkspace* w = sk_pool_entry(i);
         if (!w) break;
@@ -1187,18 +1006,16 @@ int ew_gemm3_sk_status_b256() {
 }
 namespace {
 
-// half split of small problems: see launch3.  EW_G3_SKHALF_MINK = smallest K it is used for (0 = off; A/B hook)
+// half split of small problems: see launch3.  Smallest K it is used for:
 inline int sk_half_min_k() {
     // A/B per shape at M = 7200, N = 1280 (profiles/r04_d_half_split.txt): K = 11520 conv 235 -> 222 us, K = 23040 conv 443 -> 396 us;
     // K = 5120 dense 104 -> 115 us, K = 2560 67 -> 74, temporal K = 3840 90 -> 97 (the hand-over, 2 x 320 KB per block pair, costs more
     // than the idle CUs there): on from K = 8192
-    static const int v = getenv("EW_G3_SKHALF_MINK") ? atoi(getenv("EW_G3_SKHALF_MINK")) : 8192;
-    return v;
+    return 8192;
 }
 inline bool sk_half_shape(const GemmP& p, long long tiles) {
-    static const int sk_mode = getenv("EW_G3_SK") ? atoi(getenv("EW_G3_SK")) : 1;
     const int mk = sk_half_min_k();
-    return sk_mode && mk > 0 && !(p.dbg & 4) && tiles >= 8 && 2 * tiles <= ew_cu_budget() && (2 * tiles) % 8 == 0 && (p.K / BK) % 2 == 0 && p.K >= mk;
+    return !(p.dbg & 4) && tiles >= 8 && 2 * tiles <= ew_cu_budget() && (2 * tiles) % 8 == 0 && (p.K / BK) % 2 == 0 && p.K >= mk;
 }
 template <int MODE, int EPI>
 inline bool sk_half_applies(const GemmP& p, long long tiles) {
@@ -1211,7 +1028,7 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
     q.tiles_m = ew_cdiv(p.M, BM);
     q.tiles_n = p.N / BN;
     q.band = ((long long)p.N * p.K * 2 > 3LL * 1024 * 1024) ? 4 : 0;
-    const size_t lds = (MODE == EW_A_CONV3X3H ? HALO_LDS : 2 * STAGE) + ITEMS_BYTES;
+    const size_t lds = 2 * STAGE + ITEMS_BYTES;
     static std::atomic<unsigned long long> attr_mask{0};                   // per (kernel instantiation, device)
     if (ew_status st = ew_ensure_dynamic_lds((const void*)gemm3_kernel<MODE, EPI>, (int)lds, attr_mask)) return st;
     const long long tiles = (long long)q.tiles_m * q.tiles_n;
@@ -1222,13 +1039,12 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
     // 7.03 / 3.52 / 1.77 rounds paid as 8 / 4 / 2.  When the loss is worth it, the last (T mod 256) + 256 tiles are cut along K
     // into 256 equal ranges instead (gemm3_kernel: contributor / finisher hand-over through the uncached workspace).
     SkP sk{nullptr, nullptr, 0u, 0, 0};
-    static const int sk_mode = getenv("EW_G3_SK") ? atoi(getenv("EW_G3_SK")) : 1;          // 0 = off (A/B), 1 = on, 2 = every shape
-    static const int sk_min_k = getenv("EW_G3_SK_MINK") ? atoi(getenv("EW_G3_SK_MINK")) : 1280;
+    constexpr int sk_min_k = 1280;                  // (ew_set_gemm_debug(4) forces the whole-tile schedule: the twin of the stream-K parity test)
     // Where it pays (A/B per shape on the U-Net's problems, same box): 3x3 convs at every level (-6 ... -10 %), dense / temporal
     // GEMMs with at most two tile columns and K >= 1280 (-4 ... -8 %).  With four tile columns (level 2) the blocks of an XCD
     // are out of phase along K and stop sharing the A rows and W slices in L2: +7 ... +16 % -- left on the whole-tile schedule.
-    const bool sk_shape = MODE == EW_A_CONV3X3 || MODE == EW_A_CONV3X3H || (q.tiles_n <= 2 && p.K >= sk_min_k) || sk_mode == 2;
-    if (sk_mode && sk_shape && !(MODE == EW_A_DENSE && EPI == 23) && !(p.dbg & 4) && grid == NCU && tiles > NCU && tiles % NCU != 0) {
+    const bool sk_shape = MODE == EW_A_CONV3X3 || (q.tiles_n <= 2 && p.K >= sk_min_k);
+    if (sk_shape && !(MODE == EW_A_DENSE && EPI == 23) && !(p.dbg & 4) && grid == NCU && tiles > NCU && tiles % NCU != 0) {
         const long long rounds = (tiles + NCU - 1) / NCU;
         const double loss = 1.0 - (double)tiles / ((double)NCU * rounds);
         if (loss > 0.04) {
@@ -1262,16 +1078,6 @@ ew_status launch3(const GemmP& p, hipStream_t s) {
     return ew_check_launch("ew_gemm_f16(gen3)");
 }
 
-// halo-slab loader (MODE EW_A_CONV3X3H): stride-1 "same" 3x3 convs whose 256-row tiles are whole image rows of 64 / 128 / 256 pixels
-// (levels 0 and 1 of the U-Net).  OFF by default (round 5: forward +-0, FETCH_SIZE unchanged -- the three column taps of the plain loader already hit in
-// cache; profiles/r05_f_halo_slab_*): EW_G3_HALO=1 or ew_set_gemm_debug bit 4 switches it on, bit 3 forces the plain per-tap loader; results are
-// bit-identical either way (tests/test_gpu_gemm_gen3.py::test_conv3x3_halo_slab_loader).
-inline bool halo_ok(const GemmP& p) {
-    static const int on = getenv("EW_G3_HALO") ? atoi(getenv("EW_G3_HALO")) : 0;   // off: measured at +-0 in time and in FETCH_SIZE (profiles/r05_f_*)
-    return (on || (p.dbg & 16)) && !(p.dbg & 8) && p.stride == 1 && !p.upsample && p.conv_shift == 0 && p.h_in == p.h_out && p.w_in == p.w_out &&
-           (p.w_in == 64 || p.w_in == 128 || p.w_in == 256) && (long long)p.n_img * p.h_in * p.w_in == p.M && p.M < (1 << 28);
-}
-
 // operand sets that occur in the U-Net (evoworld_amd/unet.py); any other mask runs on the smallest compiled superset
 template <int MODE>
 ew_status dispatch_epi3(const GemmP& p, hipStream_t s) {
@@ -1282,12 +1088,7 @@ ew_status dispatch_epi3(const GemmP& p, hipStream_t s) {
     const int mask = (p.rowbias ? 1 : 0) | (p.r1 ? 2 : 0) | (p.r2 ? 4 : 0);
     if (p.r1_lo || p.r2_lo || p.out_lo) {           // split-fp16 residual stream: general path with the lo companions
         // no residual operand (round 5): the row-bias enters through the accumulators' initial value, the epilogue only converts and stores
-        if (EW_G3_RB_INIT && (mask & 6) == 0) {
-            if constexpr (MODE == EW_A_CONV3X3) {
-                if (halo_ok(p)) return launch3<EW_A_CONV3X3H, 16 | 1>(p, s);
-            }
-            return launch3<MODE, 16 | 1>(p, s);
-        }
+        if ((mask & 6) == 0) return launch3<MODE, 16 | 1>(p, s);
         if constexpr (MODE == EW_A_DENSE) {
             if ((mask & 4) == 0) return launch3<MODE, 16 | 3>(p, s);
             return launch3<MODE, 16 | 7>(p, s);
@@ -1316,9 +1117,8 @@ ew_status dispatch_epi3(const GemmP& p, hipStream_t s) {
 bool EW3_NAME(ew_gemm3_wants)(const GemmP& p, hipStream_t s) {
     // smallest M: the swapped-operand V^T projections (M = C = 320 / 640 / 1280 rows of W_v against N = all tokens) measured
     // 337 -> 253 us (level 0) and 192 -> 156 us (level 1) here against generation 2's 256x160 tiles (640-byte instead of 320-byte output
-    // row pieces; profiles/r04_f_sweeps.txt); EW_G3_MINM is the A/B hook (round 3 value: 1024)
-    static const int min_m = getenv("EW_G3_MINM") ? atoi(getenv("EW_G3_MINM")) : 320;
-    if (p.N % BN != 0 || p.M < min_m) return false;
+    // row pieces; profiles/r04_f_sweeps.txt; round 3's threshold was 1024)
+    if (p.N % BN != 0 || p.M < 320) return false;
     if (BN != 320 && p.N % 320 == 0) return false;                      // the 320-wide instance takes what it can
     if ((long long)ew_cdiv(p.M, BM) * (p.N / BN) > (long long)ew_cu_budget() * (ITEMS_BYTES / 16 - 4)) return false;     // work-item table of a persistent block
     // GELU (CLIP's fc1) is only compiled into the plain dense variant: the erf code in every epilogue cost the conv variants
@@ -1331,8 +1131,8 @@ bool EW3_NAME(ew_gemm3_wants)(const GemmP& p, hipStream_t s) {
     if (p.rowbias && ((long long)p.M / max(1, p.rows_per_group) + 2) * p.ld_rowbias * 2 >= (1LL << 32)) return false;
     // one tile column and a short K: 1800 tiles = 7.03 rounds over 256 CUs cost 8, and the residual-carrying epilogue is
     // store-bound anyway -- generation 2's 256x160 tiles (14.06 -> 15 rounds) measured 5-10 % faster there
-    static const int short_rule = getenv("EW_G3_SHORT") ? atoi(getenv("EW_G3_SHORT")) : 0;     // A/B hook: 1 = gen3 also there
-    if (!short_rule && p.mode == EW_A_DENSE && p.N == BN && p.K <= 1280 && (p.r1 || p.r2)) return false;
+    // (re-measured on the round-5 kernels: 182.90 vs 182.99 ms per forward either way, profiles/r05_g_short_rule_ab_forward.txt)
+    if (p.mode == EW_A_DENSE && p.N == BN && p.K <= 1280 && (p.r1 || p.r2)) return false;
     const long long tiles = (long long)ew_cdiv(p.M, BM) * (p.N / BN);
     if (tiles * 256 >= 200LL * ew_cu_budget()) return true;      // (200 of 256 CUs busy, scaled to the CU budget)
     // fewer tiles than CUs: generation 3 only with the half split (launch3), i.e. not for the one variant compiled without it

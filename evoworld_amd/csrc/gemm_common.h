@@ -24,7 +24,7 @@ struct GemmP {
     float c_acc, c_r1, c_r2;
     int tiles_m, tiles_n;
     int band;  // generation 3: tile columns per band of the tile order (0 = plain tn-fastest order)
-    int dbg;   // experiment switches (tools/bench_kernels.py): bit0 skip output stores, bit1 skip epilogue entirely
+    int dbg;   // ew_set_gemm_debug: bit 2 (value 4) = generation 3 runs the whole-tile schedule (no stream-K tail / half split)
 };
 
 // generation 3, stream-K tail (gemm3_f16.hip), passed as a second kernel argument (GemmP is kept under 256 bytes: beyond that the

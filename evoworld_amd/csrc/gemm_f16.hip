@@ -282,6 +282,8 @@ ew_status ew_gemm2_dispatch(const GemmP& p, hipStream_t s);   // gemm2_f16.hip
 ew_status ew_gemm3_dispatch(const GemmP& p, hipStream_t s);   // gemm3_f16.hip
 bool ew_gemm3_wants(const GemmP& p, hipStream_t s);
 ew_status ew_gemm3_dispatch_b256(const GemmP& p, hipStream_t s);   // gemm3_f16.hip compiled with EW3_BN=256
+bool ew_conv_small_n_wants(const GemmP& p);                        // conv_small_n.hip: 3x3 convs with N <= 16 (conv_out)
+ew_status ew_conv_small_n_dispatch(const GemmP& p, hipStream_t s);
 bool ew_gemm3_wants_b256(const GemmP& p, hipStream_t s);
 static int g_gemm_gen = -1;
 char g_gemm_last_kernel[64] = "";          // rocprof-style name of the kernel the last ew_gemm_f16 call launched
@@ -290,10 +292,7 @@ static int g_gemm_dbg = 0;
 extern "C" void ew_set_gemm_debug(int d) { g_gemm_dbg = d; }
 extern "C" void ew_set_gemm_generation(int gen) { g_gemm_gen = gen; }
 extern "C" int ew_get_gemm_generation(void) {
-    if (g_gemm_gen < 0) {
-        const char* e = getenv("EW_GEMM_GEN");
-        g_gemm_gen = e ? atoi(e) : 3;
-    }
+    if (g_gemm_gen < 0) g_gemm_gen = 3;
     return g_gemm_gen;
 }
 
@@ -345,6 +344,8 @@ extern "C" ew_status ew_gemm_f16(const ew_gemm_args* a, void* stream) {
     p.band = 0;
     p.dbg = g_gemm_dbg;
     hipStream_t s = (hipStream_t)stream;
+    // 3x3 convs with a handful of output channels (conv_out: N = 4) have their own kernel (round 6); generation 1 stays the independent cross-check
+    if (ew_get_gemm_generation() >= 2 && ew_conv_small_n_wants(p)) return ew_conv_small_n_dispatch(p, s);
     // generation 3 (256x320 tile) where it applies and fills the chip, generation 2 otherwise
     if (ew_get_gemm_generation() >= 3 && ew_gemm3_wants(p, s)) return ew_gemm3_dispatch(p, s);
     if (ew_get_gemm_generation() >= 3 && ew_gemm3_wants_b256(p, s)) return ew_gemm3_dispatch_b256(p, s);

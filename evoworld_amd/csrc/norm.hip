@@ -21,7 +21,7 @@ namespace {
 // x_lo (may be null): lo8 companion of a split residual stream (common.h: one byte per element, same element strides).
 // ---------------------------------------------------------------------------------------------
 inline int gn_chunks(int n_slabs, int rows) {
-    static const int target = getenv("EW_GN_BLOCKS") ? atoi(getenv("EW_GN_BLOCKS")) : 640;     // A/B hook
+    constexpr int target = 640;
     int want = (target + n_slabs - 1) / n_slabs;               // ~2.5 blocks per CU over the whole launch
     const int cap = (rows + 63) / 64;                          // at least 64 rows per chunk
     if (want > cap) want = cap;
@@ -51,10 +51,7 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, const int8_t* __restr
     // eight independent 16-byte loads in flight per thread (one dependent load per iteration ran at 3.3 TB/s, four at 3.8)
     int r = r0 + pl;
     if (base_lo) {
-#ifndef EW_GN_STATS_UNROLL
-#define EW_GN_STATS_UNROLL 8      /* round 4 A/B: level-0 statistics pass 109 -> 102.5 us (profiles/r04_f_sweeps.txt) */
-#endif
-        constexpr int UL = EW_GN_STATS_UNROLL;      // rows in flight per thread on the hi + lo8 path (A/B: 4 vs 8)
+        constexpr int UL = 8;                       // rows in flight per thread on the hi + lo8 path (round 4 A/B, 4 vs 8: level-0 statistics pass 109 -> 102.5 us, profiles/r04_f_sweeps.txt)
         for (; r + (UL - 1) * PL < r1; r += UL * PL) {
             f16x8 val[UL];
             u32x2 vlo[UL];

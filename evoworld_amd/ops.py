@@ -122,13 +122,12 @@ def streamk_init():
     """Best effort: allocate generation 3's stream-K workspace for (current device, current stream) once, outside any kernel
     launch path (ew_gemm_streamk_init).  Nothing depends on it succeeding -- a launch without a workspace runs the whole-tile
     schedule -- so a full pool (64 (device, stream) pairs per process) or a failed allocation only warns.  Skipped when the
-    tail split cannot be used (EW_GEMM_GEN != 3, EW_G3_SK=0) and while the current stream is being captured into a graph
+    tail split cannot be used (generation != 3) and while the current stream is being captured into a graph
     (allocation + memset are illegal there; call it on the capture stream BEFORE the capture to get the tail inside the graph)."""
-    import os
     key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     if key in _sk_ready:
         return
-    if _lib.load().ew_get_gemm_generation() != 3 or os.environ.get("EW_G3_SK", "1") == "0":
+    if _lib.load().ew_get_gemm_generation() != 3:
         return
     if torch.cuda.is_current_stream_capturing():
         return
@@ -483,39 +482,10 @@ def attn_small(q, k, v, o, n_seq, S, heads, D, ld, ld_o, scale):
     return o
 
 
-def quant_rows_fp8(x):
-    """x fp16 [M,K] -> (q uint8 [M,K] holding OCP e4m3 bytes, scale fp32 [M]) with x ~= q * scale[:, None]."""
-    lib = _lib.load()
-    _req(x, torch.float16, "x")
-    M, K = x.shape
-    q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
-    sc = torch.empty(M, dtype=torch.float32, device=x.device)
-    _lib.check(lib.ew_quant_rows_fp8(_ptr(x), _ptr(q), _ptr(sc), M, K, _stream()), "ew_quant_rows_fp8")
-    return q, sc
-
-
-def gemm_fp8(a, a_scale, w, w_scale, out=None):
-    """a uint8 [M,K] (e4m3), w uint8 [N,K] (e4m3), scales fp32 -> fp16 [M,N] = (a @ w^T) * a_scale[:,None] * w_scale[None]."""
-    lib = _lib.load()
-    M, K = a.shape
-    N = w.shape[0]
-    if out is None:
-        out = torch.empty(M, N, dtype=torch.float16, device=a.device)
-    _lib.check(lib.ew_gemm_fp8(_ptr(a), _ptr(a_scale), _ptr(w), _ptr(w_scale), _ptr(out), M, N, K, out.stride(0), _stream()),
-               "ew_gemm_fp8")
-    return out
-
-
-def ff_pack(w1, b1, w2, ln=None):
+def ff_pack(w1, b1, w2):
     """Weights of one GEGLU feed-forward (w1 [2*H, C] value rows then gate rows, b1 [2*H], w2 [C, H]; fp32 or fp16, on the
-    device) -> (w1p, b1p, w2p) fp16 in the LDS-image packs ew_ff_geglu320_f16 streams (layout: csrc/ff_fused.hip).
-    ln = (gamma, beta) folds the affine part of the LayerNorm in front of the feed-forward into the up-projection (in fp32, before the
-    single rounding to fp16): LN(x) W1^T + b1 = ((x - mean) rstd) (W1 diag(gamma))^T + (b1 + W1 beta) -- for ff_geglu320(..., ln_folded=True)."""
+    device) -> (w1p, b1p, w2p) fp16 in the LDS-image packs ew_ff_geglu320_f16 streams (layout: csrc/ff_fused.hip)."""
     dev = w1.device
-    if ln is not None:
-        g, bt = ln[0].float().to(dev), ln[1].float().to(dev)
-        b1 = b1.float() + w1.float() @ bt
-        w1 = w1.float() * g[None, :]
     H2, C = w1.shape
     H = H2 // 2
     assert C == 320 and H == 1280 and tuple(w2.shape) == (C, H)
@@ -542,22 +512,12 @@ def ff_pack(w1, b1, w2, ln=None):
     return w1p, b1p, w2p
 
 
-def ff_geglu320(x, pack, b2, out, *, rowbias=None, rows_per_group=1, ld_rowbias=None, r1=None, r2=None, c_acc=1.0, c_r1=1.0, c_r2=1.0,
-                ln=None, ln_eps=1e-5, addvec=None, add_rows_per_group=1, ln_folded=False):
-    """out = c_acc * (GEGLU(n W1^T + b1) W2^T + b2 + rowbias) + c_r1 * r1 + c_r2 * r2 for 320-channel tokens, one kernel
-    (ew_ff_geglu320_f16): pack = ff_pack(...); r1 / r2 / out tensors or `Res`.  n = x (fp16 [M, 320]), or with ln = (gamma, beta):
-    n = LayerNorm(x + addvec[m // add_rows_per_group]) computed in the kernel's prologue from the stream x (tensor or `Res`); with
-    ln_folded=True: n = (x - mean) * rstd of the hi plane of x, the LayerNorm's gamma / beta folded into the pack (ff_pack(..., ln=...))."""
+def ff_geglu320(x, pack, b2, out, *, rowbias=None, rows_per_group=1, ld_rowbias=None, r1=None, r2=None, c_acc=1.0, c_r1=1.0, c_r2=1.0):
+    """out = c_acc * (GEGLU(x W1^T + b1) W2^T + b2 + rowbias) + c_r1 * r1 + c_r2 * r2 for 320-channel tokens, one kernel
+    (ew_ff_geglu320_f16): x fp16 [M, 320] (the LayerNorm output), pack = ff_pack(...); r1 / r2 / out tensors or `Res`."""
     lib = _lib.load()
-    x, x_lo = _hl(x)
     _req(x, torch.float16, "x")
     a = _lib.FfArgs()
-    if ln is not None:
-        a.x_lo, a.ln_gamma, a.ln_beta, a.addvec = _ptr(x_lo), _ptr(ln[0]), _ptr(ln[1]), _ptr(addvec)
-        a.add_rows_per_group, a.ln_eps = add_rows_per_group, ln_eps
-    if ln_folded:
-        assert ln is None and addvec is None, "ln_folded: the LayerNorm's gamma / beta live in the pack (ff_pack(..., ln=...))"
-        a.ln_folded, a.ln_eps = 1, ln_eps
     r1h, r1l = _hl(r1)
     r2h, r2l = _hl(r2)
     oh, ol = _hl(out)

@@ -235,7 +235,7 @@ def random_state_dict(cfg, seed=0, device="cpu"):
 class UNetSpatioTemporalConditionModel:
     def __init__(self, **config):
         cfg = dict(DEFAULT_CONFIG)
-        cfg.update({k: v for k, v in config.items() if k != "qkv_fp8"})
+        cfg.update(config)
         self._cfg = cfg
         self.config = SimpleNamespace(**cfg)
         self.arch = _arch(cfg)
@@ -249,21 +249,20 @@ class UNetSpatioTemporalConditionModel:
         mode = os.environ.get("EW_RESIDUAL", "split")
         self.split_residual = mode != "fp16"
         self.split_heads = mode == "split"     # also split the stream tensors produced WITHOUT a residual operand
-        # BASELINE.json configs[4]: q / k / v projections on the fp8 (e4m3) MFMA path (per-token activation scales,
-        # per-output-channel weight scales); off by default -- it changes the numerics contract (tests/test_gpu_fp8.py)
-        self.qkv_fp8 = bool(config.get("qkv_fp8", os.environ.get("EW_QKV_FP8", "0") == "1"))
+        # (BASELINE.json configs[4]'s fp8 q / k / v projections were built in rounds 2-4, measured slower than the fp16 GEMMs and 6x outside the parity
+        # tolerance, and removed in round 6: tools/experiments/fp8_qkv/; configs[4] runs fp16)
         # round 4: q|k projections carry sqrt(scale * log2 e) in their epilogue and the attention kernel's MFMA subtracts the running max
-        # (ew_attn_spatial_log2_f16); EW_ATTN_LOG2=0 restores the scale-and-shift form
-        self.attn_log2 = os.environ.get("EW_ATTN_LOG2", "1") == "1"
+        # (ew_attn_spatial_log2_f16); attn_log2 = False (attribute, A/B only) restores the scale-and-shift form on ew_attn_spatial_f16
+        self.attn_log2 = True
         # conv1 output of every resblock (the GroupNorm input between the two 3x3 convs) carried split too: in the per-tensor
         # ablation (tests/analysis_fp16_floor.py --per-tensor, tag res_h1) its fp16 rounding was the largest storage term left
-        # (0.15e-6 of squared rel-L2 against 0.56e-6 for fp16 MFMA operands alone); EW_SPLIT_H1=0 restores the plain fp16 tensor
-        self.split_h1 = self.split_heads and os.environ.get("EW_SPLIT_H1", "1") != "0"
+        # (0.15e-6 of squared rel-L2 against 0.56e-6 for fp16 MFMA operands alone; 8.9e-4 -> 8.2e-4 per forward for +1.0 ms)
+        self.split_h1 = self.split_heads
         # EW_FUSED_FF: the level-0 feed-forwards (GEGLU pair + residual epilogue) through ONE kernel, ew_ff_geglu320_f16: 0 = LayerNorm
-        # + two GEMMs, 1 = LayerNorm kernel + fused kernel (default), 2 = LayerNorm in the fused kernel's prologue.  Mode 1 keeps
-        # the 1.18 GB GEGLU intermediate of each of the 15 level-0 feed-forwards out of HBM (-35 GB per forward) and measures
-        # -1.0 ms per forward in place (A/B in one process); mode 2 is +9 ms (profiles/r03_e_*)
-        self.fused_ff = int(os.environ.get("EW_FUSED_FF", "1"))
+        # + two GEMMs (A/B baseline), 1 = LayerNorm kernel + fused kernel (default).  Mode 1 keeps the 1.18 GB GEGLU intermediate of each
+        # of the 15 level-0 feed-forwards out of HBM (-35 GB per forward) and measures -1.9 ms per forward in place (A/B in one process).
+        # (Modes 2 / 3 -- LayerNorm in the fused kernel's prologue, +9 ms; LayerNorm folded into the pack, +1.1 ms -- were removed in round 6.)
+        self.fused_ff = 1 if os.environ.get("EW_FUSED_FF", "1") != "0" else 0
         # Round 5: fp16 operand rounding removed where it is (nearly) free.  An fp32 checkpoint (what the reference runs, unified_loop_consistency.py:188)
         # rounded to fp16 once costs as much squared distance to the fp32 oracle as all activation operands together, and per layer group (tiny
         # config, tests/analysis_fp16_floor.py --per-group) conv_in + conv_out + the level-0 proj_in / proj_out carry ~40 % of it for < 1 % of the flops:
@@ -325,8 +324,8 @@ class UNetSpatioTemporalConditionModel:
         """Every device tensor of the packed weight set, in a fixed order (3.04 GB fp16 for the full U-Net)."""
         out = []
 
-        def walk(v):      # dicts in key order, tuples / lists in position order, at any nesting depth (the fp8 q/k/v packs are
-            if isinstance(v, torch.Tensor):                       # (weights, scales) tuples INSIDE the per-block dicts)
+        def walk(v):      # dicts in key order, tuples / lists in position order, at any nesting depth
+            if isinstance(v, torch.Tensor):
                 out.append(v)
             elif isinstance(v, dict):
                 for n in sorted(v, key=str):
@@ -455,10 +454,6 @@ class UNetSpatioTemporalConditionModel:
                     d["s_qk"], d["s_v"] = h(torch.cat([q, k_])), h(v)
                 else:
                     d["t_qkv"] = h(torch.cat([q, k_, v]))
-                if self.qkv_fp8:
-                    for nm, wt in ((("s_qk8", torch.cat([q, k_])), ("s_v8", v)) if tag == "s" else (("t_qkv8", torch.cat([q, k_, v])),)):
-                        sc = (wt.abs().amax(dim=1).clamp_min(1e-12) / 448.0).contiguous()          # per-output-channel scale
-                        d[nm] = ((wt / sc[:, None]).to(torch.float8_e4m3fn).view(torch.uint8).contiguous(), sc)
                 d[f"{tag}_ow"], d[f"{tag}_ob"] = h(f32(b + ".attn1.to_out.0.weight")), h(f32(b + ".attn1.to_out.0.bias"))
                 # cross attention with ONE key/value token: out = to_out(to_v(ctx)) -> fold the two matrices
                 cv_w.append(f32(b + ".attn2.to_out.0.weight") @ f32(b + ".attn2.to_v.weight"))
@@ -474,9 +469,6 @@ class UNetSpatioTemporalConditionModel:
                     # level 0: the LayerNorm + GEGLU feed-forward pairs run as ONE kernel (ew_ff_geglu320_f16) on LDS-image packs
                     for nm, ff in ((f"{tag}_ffp", ".ff"),) + (((f"{tag}_fip", ".ff_in"),) if tag == "t" else ()):
                         d[nm] = ops.ff_pack(f32(b + ff + ".net.0.proj.weight"), f32(b + ff + ".net.0.proj.bias"), f32(b + ff + ".net.2.weight"))
-                    if self.fused_ff == 3:      # norm3 folded into the up-projection of .ff (round 4, EW_FUSED_FF=3): W1 diag(gamma), b1 + W1 beta
-                        d[f"{tag}_ffp_ln"] = ops.ff_pack(f32(b + ".ff.net.0.proj.weight"), f32(b + ".ff.net.0.proj.bias"), f32(b + ".ff.net.2.weight"),
-                                                         ln=(f32(b + ".norm3.weight"), f32(b + ".norm3.bias")))
             W[t.p] = d
         W["cv_w"], W["cv_b"] = h(torch.cat(cv_w)), h(torch.cat(cv_b))
         self._cv_total = off
@@ -590,16 +582,11 @@ class UNetSpatioTemporalConditionModel:
         h = self._lin2(hn, d["piw"], d["pib"], self._res(rows, C, dev, head=True))
         # --- spatial BasicTransformerBlock ---
         n1 = ops.layernorm(h, d["s_norm1g"], d["s_norm1b"])
-        if self.qkv_fp8:
-            n8, nsc = ops.quant_rows_fp8(n1)
-            qk = ops.gemm_fp8(n8, nsc, *d["s_qk8"])
-            vt = ops.gemm_fp8(d["s_v8"][0], d["s_v8"][1], n8, nsc)   # V^T = W_v X^T: operand roles swapped
-        else:
-            qk = ops.linear(n1, d["s_qk"], c_acc=ops.QK_LOG2_PRESCALE if self.attn_log2 else 1.0)
-            vt = torch.empty(C, rows, dtype=torch.float16, device=dev)
-            ops.gemm(d["s_v"], n1, vt, M=C, N=rows, c1=C, lda=C)      # V^T = W_v X^T (swapped operands)
+        qk = ops.linear(n1, d["s_qk"], c_acc=ops.QK_LOG2_PRESCALE if self.attn_log2 else 1.0)
+        vt = torch.empty(C, rows, dtype=torch.float16, device=dev)
+        ops.gemm(d["s_v"], n1, vt, M=C, N=rows, c1=C, lda=C)      # V^T = W_v X^T (swapped operands)
         ao = torch.empty(rows, C, dtype=torch.float16, device=dev)
-        if self.attn_log2 and not self.qkv_fp8:
+        if self.attn_log2:
             ops.attn_spatial_log2(qk, qk[:, C:], vt, ao, N, S, t.heads, 2 * C, rows, C)
         else:
             ops.attn_spatial(qk, qk[:, C:], vt, ao, N, S, t.heads, 2 * C, rows, C)
@@ -608,11 +595,7 @@ class UNetSpatioTemporalConditionModel:
         h = ops.linear(ao, d["s_ow"], d["s_ob"], out=self._res(rows, C, dev), rowbias=cv_s, rows_per_group=T * S,
                        ld_rowbias=self._cv_total, r1=h, ld_r1=C)
         fused = self.fused_ff if "s_ffp" in d else 0     # level 0: LayerNorm + GEGLU up-projection + down-projection + residual in one kernel
-        if fused == 3:      # LayerNorm folded: the kernel normalises the hi plane of the stream in registers, gamma / beta live in the pack
-            h = ops.ff_geglu320(h, d["s_ffp_ln"], d["s_f2b"], self._res(rows, C, dev), r1=h, ln_folded=True)
-        elif fused == 2:
-            h = ops.ff_geglu320(h, d["s_ffp"], d["s_f2b"], self._res(rows, C, dev), r1=h, ln=(d["s_norm3g"], d["s_norm3b"]))
-        elif fused:
+        if fused:
             n3 = ops.layernorm(h, d["s_norm3g"], d["s_norm3b"])
             h = ops.ff_geglu320(n3, d["s_ffp"], d["s_f2b"], self._res(rows, C, dev), r1=h)
         else:
@@ -627,10 +610,7 @@ class UNetSpatioTemporalConditionModel:
         # hm after ff_in and after the temporal attention are the two stream tensors whose fp16 rounding matters least
         # (tests/analysis_fp16_floor.py per-tensor ablation: +0.036e-6 and +0.021e-6 of squared rel-L2 against 0.25e-6 for a
         # resblock output): they are kept as plain fp16, which saves their lo halves' write + two reads
-        if fused == 2:
-            hm = ops.ff_geglu320(h, d["t_fip"], d["t_fi2b"], Res.empty(rows, C, dev, False), r1=h, rowbias=pos, rows_per_group=S,
-                                 ld_rowbias=C, ln=(d["t_norm_ing"], d["t_norm_inb"]), addvec=pos, add_rows_per_group=S)
-        elif fused:
+        if fused:
             nin = ops.layernorm(h, d["t_norm_ing"], d["t_norm_inb"], addvec=pos, rows_per_group=S)
             hm = ops.ff_geglu320(nin, d["t_fip"], d["t_fi2b"], Res.empty(rows, C, dev, False), r1=h, rowbias=pos, rows_per_group=S, ld_rowbias=C)
         else:
@@ -640,19 +620,13 @@ class UNetSpatioTemporalConditionModel:
                             rows_per_group=S, ld_rowbias=C)
             del ffh
         n1 = ops.layernorm(hm, d["t_norm1g"], d["t_norm1b"])
-        qkv = ops.gemm_fp8(*ops.quant_rows_fp8(n1), *d["t_qkv8"]) if self.qkv_fp8 else ops.linear(n1, d["t_qkv"])
+        qkv = ops.linear(n1, d["t_qkv"])
         ops.attn_temporal(qkv, qkv[:, C:], qkv[:, 2 * C:], ao, B, T, S, t.heads, 3 * C, C)
         del qkv
         hm = ops.linear(ao, d["t_ow"], d["t_ob"], out=Res.empty(rows, C, dev, False), rowbias=cv_t, rows_per_group=T * S,
                         ld_rowbias=self._cv_total, r1=hm, ld_r1=C)
         a = d["mix"]  # AlphaBlender: a*x_spatial + (1-a)*x_temporal, x_temporal = hm + ff(..); hb is only a GEMM operand
-        if fused == 3:
-            hb = ops.ff_geglu320(hm, d["t_ffp_ln"], d["t_f2b"], torch.empty(rows, C, dtype=torch.float16, device=dev), c_acc=1.0 - a, r1=hm,
-                                 c_r1=1.0 - a, r2=h, c_r2=a, ln_folded=True)
-        elif fused == 2:
-            hb = ops.ff_geglu320(hm, d["t_ffp"], d["t_f2b"], torch.empty(rows, C, dtype=torch.float16, device=dev), c_acc=1.0 - a, r1=hm,
-                                 c_r1=1.0 - a, r2=h, c_r2=a, ln=(d["t_norm3g"], d["t_norm3b"]))
-        elif fused:
+        if fused:
             n3 = ops.layernorm(hm, d["t_norm3g"], d["t_norm3b"])
             hb = ops.ff_geglu320(n3, d["t_ffp"], d["t_f2b"], torch.empty(rows, C, dtype=torch.float16, device=dev), c_acc=1.0 - a, r1=hm,
                                  c_r1=1.0 - a, r2=h, c_r2=a)

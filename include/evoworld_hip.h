@@ -93,7 +93,7 @@ typedef struct ew_gemm_args {
 
 ew_status ew_gemm_f16(const ew_gemm_args* args, void* stream);
 /* Kernel generation behind ew_gemm_f16: 1 = 128x160 tile, 2 blocks/CU; 2 = persistent 3-stage ring, 256x160 / 128x256 tiles;
- * 3 (default; env EW_GEMM_GEN overrides) = persistent 256x320 (and 256x256) tile with a stream-K tail where N % 320 == 0 (or
+ * 3 (default) = persistent 256x320 (and 256x256) tile with a stream-K tail where N % 320 == 0 (or
  * N % 256 == 0) and the problem fills the chip, generation 2 for everything else.  Same arguments, same results to rounding;
  * kept selectable for A/B measurements. */
 void ew_set_gemm_generation(int gen);
@@ -101,8 +101,9 @@ int ew_get_gemm_generation(void);
 /* Debug aid for measurement tools (bench.py): rocprof-style name of the kernel variant the last ew_gemm_f16 call on this
    thread's library instance launched, e.g. "gemm3_kernel<0, 8>".  Not part of the reference surface. */
 const char* ew_gemm_last_kernel(void);
-void ew_set_gemm_debug(int flags);   /* measurement-only switches (bit0: skip stores, bit1: skip epilogue, bit2: no stream-K tail, bit3 / bit4: force the plain per-tap loader /
-                                        the halo-slab loader (an experiment, off by default) of the stride-1 3x3 convs -- same results bit for bit); 0 = normal */
+void ew_set_gemm_debug(int flags);   /* bit 2 (value 4): generation 3 runs the whole-tile schedule -- no stream-K tail, no half split -- the twin the stream-K parity
+                                        test compares against (same results up to fp32 summation order); 0 = normal.  (ABI <= 9 also had result-destroying
+                                        ablation bits 0 / 1 and the halo-slab loader bits 3 / 4: removed in ABI 10.) */
 /* Generation 3 splits the last round of output tiles along K over its 256 persistent workgroups when whole-tile rounds would
  * leave > 4 % of the chip idle (stream-K tail: fp32 partial accumulators handed over through a library-owned uncached
  * workspace, one per (device, stream), allocated on first use: 84 MB + 67 MB for the 256-wide instance).  Deterministic: the
@@ -120,7 +121,8 @@ ew_status ew_gemm_streamk_init(void* stream);
  * subset of the CUs (ew_stream_create_cu_mask: two independent forwards -- the two rows of the CFG batch the reference concatenates,
  * evoworld/pipeline/pipeline_evoworld.py:689-711 -- side by side on disjoint halves of the chip) sets the budget to that subset's size
  * first: with more workgroups than CUs a stream-K finisher could wait for a contributor that is not resident.  Process-wide; a multiple
- * of 8 in [8, 256].  Returns the previous value. */
+ * of 8 in [8, 256].  Returns the previous value.  Set it BEFORE any stream of the partition is in use: the value is atomic, but a launch reads it
+ * more than once, so a change racing a launch on another thread may size that launch inconsistently. */
 int ew_set_cu_budget(int n_cus);
 int ew_get_cu_budget(void);
 /* A HIP stream whose kernels only run on CUs [first_cu, first_cu + n_cus) of the CU-mask bit order (hipExtStreamCreateWithCUMask).
@@ -133,7 +135,7 @@ ew_status ew_stream_destroy(void* stream);
  * = diffusers FeedForward(320, activation_fn="geglu") (net.0 GEGLU projection 320 -> 2 x 1280, net.2 Linear 1280 -> 320) of
  * BasicTransformerBlock.ff / TemporalBasicTransformerBlock.ff_in / .ff (instantiated via evoworld/trainer/unet_plucker.py:161-233)
  * with the residual / AlphaBlender epilogue of ew_gemm_f16; the 1280-wide intermediate never goes to HBM.  x: fp16 [M, 320]
- * (the LayerNorm output, or the stream itself with the LayerNorm prologue below); w1p / b1p / w2p: the weights in the kernel's LDS-image packs (layout: csrc/ff_fused.hip, built by
+ * (the LayerNorm output); w1p / b1p / w2p: the weights in the kernel's LDS-image packs (layout: csrc/ff_fused.hip, built by
  * evoworld_amd.ops.ff_pack); b2 fp16 [320]; r1 / r2 / out [M, 320] with optional lo8 companions as in ew_gemm_args. */
 typedef struct ew_ff_args {
     const void* x;
@@ -152,22 +154,9 @@ typedef struct ew_ff_args {
     int M, C, hidden;      /* C = 320, hidden = 1280 */
     int rows_per_group, ld_rowbias;
     float c_acc, c_r1, c_r2;
-    /* Optional LayerNorm prologue (ln_gamma != NULL): x is then the residual stream (hi fp16 + optional lo8 companion x_lo), the
-     * kernel computes LayerNorm(x + addvec[m / add_rows_per_group]) (addvec: fp16 [G, 320] or NULL -- the time_pos_embed of
-     * TemporalBasicTransformerBlock.norm_in) with ln_gamma / ln_beta / ln_eps in registers, exactly as ew_layernorm_f16 does, and
-     * feeds it to the up-projection: the normalised tensor is never written either. */
-    const void* x_lo;
-    const void* ln_gamma;
-    const void* ln_beta;
-    const void* addvec;
-    int add_rows_per_group;
-    float ln_eps;
-    /* ABI 7 (round 4).  ln_folded != 0 (ln_gamma must be NULL): x is the hi plane of the stream; the kernel normalises every row to
-     * zero mean / unit variance (two-pass fp32 statistics over the fp16 values, eps = ln_eps) in registers, and the LayerNorm's affine
-     * part is expected FOLDED into the packs: W1 diag(gamma) and b1 + W1 beta (evoworld_amd.ops.ff_pack(..., ln=(gamma, beta))).  No
-     * operand loads in the prologue -- the per-tile gamma / beta / addvec loads are what made the ln_gamma form slower than a separate
-     * ew_layernorm_f16 launch. */
-    int ln_folded;
+    /* (ABI 5-9 carried an optional LayerNorm prologue here -- x_lo / ln_gamma / ln_beta / addvec / add_rows_per_group / ln_eps / ln_folded; both
+     * forms measured slower than the separate ew_layernorm_f16 launch on the final kernels (+9 ms and +1.1 ms per forward)
+     * and were removed in ABI 10.) */
 } ew_ff_args;
 ew_status ew_ff_geglu320_f16(const ew_ff_args* args, void* stream);
 
@@ -298,13 +287,10 @@ ew_status ew_vit_patchify_f16(const float* x, void* out, int N, int S, int P, in
 ew_status ew_attn_small_f16(const void* q, const void* k, const void* v, void* o, int n_seq, int S, int heads, int D, int ld,
                             int ld_o, float scale, void* stream);
 
-/* Optional fp8 (OCP e4m3) projections for the attention q / k / v GEMMs (BASELINE.json configs[4]).  Off by default; stated
- * tolerance in tests/test_gpu_fp8.py.  ew_quant_rows_fp8: x fp16 [rows,K] -> q fp8 [rows,K], scale[row] = amax(row)/448.
- * ew_gemm_fp8: out[m][n] = (sum_k a[m][k]*w[n][k]) * a_scale[m] * w_scale[n] (fp32 accumulate on v_mfma_f32_16x16x32_fp8_fp8,
- * fp16 out, row stride ld_out).  K % 64 == 0, N % 4 == 0.  Swapping the operand roles yields the transposed product (V^T). */
-ew_status ew_quant_rows_fp8(const void* x, void* q, float* scale, int rows, int K, void* stream);
-ew_status ew_gemm_fp8(const void* a, const float* a_scale, const void* w, const float* w_scale, void* out, int M, int N, int K,
-                      long long ld_out, void* stream);
+/* (ABI 3-9 exported ew_quant_rows_fp8 / ew_gemm_fp8: optional fp8 (OCP e4m3) q / k / v projections for BASELINE.json configs[4].  Measured slower
+ * than the fp16 generation-3 GEMMs in rounds 2-4 (2062 vs 1950 ms per forward at the configs[4] size; the projections are HBM- / epilogue-bound,
+ * halving operand bytes buys nothing) and 6x outside the parity tolerance: removed from the library in ABI 10 -- configs[4] runs fp16.  The
+ * kernels and their test live on under tools/experiments/fp8_qkv/.) */
 
 /* Plücker embedding: out[n, 0:3, y, x] = R_n d(y,x); out[n, 3:6] = t_n x (R_n d)  (fp32).
  * rays [H,W,3] fp32, c2w [N,3,4] fp32 -> out [N,6,H,W] fp32.

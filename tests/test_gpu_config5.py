@@ -69,7 +69,7 @@ def test_full_width_unet_T49_at_128x256_latents_properties():
     attention, > 4 GB tensors on the 64-bit-safe kernels.  The fp32 CPU oracle would take hours at this size, so the check is
     by properties: finiteness, independence of the CFG halves (B=1 run == second half of the B=2 run up to tile-shape rounding
     noise), agreement of two kernel families (default vs generation-1 GEMMs), and run-to-run bit-reproducibility.  Also
-    prints the in-process fp16 vs fp8-QKV forward time at this size (fp8 q/k/v stays off by default)."""
+    prints the forward time at this size (fp16: the fp8 q/k/v option of rounds 2-4 was removed in round 6, tools/experiments/fp8_qkv/)."""
     import time
     from evoworld_amd import _lib
     from evoworld_amd.unet import UNetSpatioTemporalConditionModel
@@ -107,9 +107,3 @@ def test_full_width_unet_T49_at_128x256_latents_properties():
     print(f"config-5 FULL WIDTH: default vs generation-1 GEMMs rel-L2 {e2:.2e}")
     assert e2 < 3e-3
     del b, one
-    unet8 = UNetSpatioTemporalConditionModel.from_random(seed=0, device=DEV, num_frames=49, qkv_fp8=True)
-    c, _ = fwd(unet8)
-    c, t8 = fwd(unet8)
-    e8 = rel_l2(c.cpu(), a.cpu())
-    print(f"config-5 FULL WIDTH: fp8 (e4m3) q/k/v projections {t8 * 1e3:.0f} ms vs fp16 {t16 * 1e3:.0f} ms; rel-L2 fp8 vs fp16 {e8:.2e}")
-    assert torch.isfinite(c).all() and e8 < 2e-2

@@ -115,72 +115,3 @@ def test_fused_ff_is_deterministic_and_times():
     pair = t(lambda: _two_gemm(x, w1, b1, w2, b2, o2, r1=h, ld_r1=C))
     fl = 2.0 * M * C * 2560 + 2.0 * M * 1280 * C
     print(f"level-0 feed-forward (460800 tokens): fused {fused:.3f} ms ({fl / fused / 1e9:.0f} TF/s) vs two GEMMs {pair:.3f} ms ({fl / pair / 1e9:.0f} TF/s)")
-
-
-@pytest.mark.parametrize("form,M", [("s_ff", 460800), ("t_ffin", 25600 + 50), ("t_ff", 25600)])
-def test_fused_ff_with_layernorm_prologue(form, M):
-    """LayerNorm (+ per-frame add vector) in the kernel's prologue == ew_layernorm_f16 followed by the fused kernel without it."""
-    from evoworld_amd import ops
-    C = 320
-    w1, b1, w2, b2 = _weights(30)
-    pack = ops.ff_pack(w1, b1, w2)
-    gm, bt = (torch.rand(C, generator=_g(7)) + 0.5).half().to(DEV), (torch.rand(C, generator=_g(8)) - 0.5).half().to(DEV)
-    h = ops.Res.from_float((torch.randn(M, C, generator=_g(1)) * 2 + 0.3).to(DEV))
-    hm = (torch.randn(M, C, generator=_g(2)) * 2).half().to(DEV)
-    S = 64
-    pos = torch.randn((M + S - 1) // S, C, generator=_g(3)).half().to(DEV)
-    if form == "s_ff":
-        x, kw, lnkw = h, dict(r1=h), {}
-        mk = lambda: ops.Res.empty(M, C, DEV, True)
-    elif form == "t_ffin":
-        x, kw, lnkw = h, dict(r1=h, rowbias=pos, rows_per_group=S, ld_rowbias=C), dict(addvec=pos, rows_per_group=S)
-        mk = lambda: torch.empty(M, C, dtype=torch.float16, device=DEV)
-    else:
-        a = 0.37
-        x, kw, lnkw = hm, dict(c_acc=1 - a, r1=hm, c_r1=1 - a, r2=h, c_r2=a), {}
-        mk = lambda: torch.empty(M, C, dtype=torch.float16, device=DEV)
-    n = ops.layernorm(x, gm, bt, **lnkw)
-    want, got = mk(), mk()
-    ops.ff_geglu320(n, pack, b2, want, **kw)
-    ops.ff_geglu320(x, pack, b2, got, ln=(gm, bt), ln_eps=1e-5, addvec=lnkw.get("addvec"), add_rows_per_group=lnkw.get("rows_per_group", 1), **kw)
-    a_, b_ = (got.float(), want.float())
-    e = rel_l2(a_.cpu(), b_.cpu())
-    print(f"fused feed-forward with LayerNorm prologue {form} M={M}: rel-L2 vs separate LayerNorm kernel {e:.2e}")
-    assert torch.isfinite(a_).all() and e < 1e-4
-
-
-@pytest.mark.parametrize("form,M", [("s_ff", 460800), ("t_ff", 25600 + 50)])
-def test_fused_ff_with_folded_layernorm(form, M):
-    """Round 4 (EW_FUSED_FF=3): LayerNorm folded into the up-projection -- gamma / beta in the pack (W1 diag(gamma), b1 + W1 beta), the
-    kernel normalises the hi plane of the stream in registers -- against fp32 torch LayerNorm + GEGLU feed-forward on a row sample and
-    against the shipped LayerNorm-kernel + fused-kernel pair (which reads hi + lo8 and rounds the normalised tensor AFTER gamma / beta:
-    another rounding point, so the two agree to fp16 rounding noise, not bit for bit).  Includes a large-mean row band (mean / std = 30)."""
-    from evoworld_amd import ops
-    C = 320
-    w1, b1, w2, b2 = _weights(40)
-    gm, bt = (torch.rand(C, generator=_g(7)) + 0.5).half().to(DEV), (torch.rand(C, generator=_g(8)) - 0.5).half().to(DEV)
-    pack, pack_ln = ops.ff_pack(w1, b1, w2), ops.ff_pack(w1, b1, w2, ln=(gm, bt))
-    hf = torch.randn(M, C, generator=_g(1)) * 2 + 0.3
-    hf[: M // 8] += 60.0                                   # rows whose mean dwarfs their spread
-    h = ops.Res.from_float(hf.to(DEV))
-    hm = hf.half().to(DEV)
-    a = 0.37
-    if form == "s_ff":
-        x, kw, mk = h, dict(r1=h), (lambda: ops.Res.empty(M, C, DEV, True))
-    else:
-        x, kw, mk = hm, dict(c_acc=1 - a, r1=hm, c_r1=1 - a, r2=h, c_r2=a), (lambda: torch.empty(M, C, dtype=torch.float16, device=DEV))
-    want, got = mk(), mk()
-    ops.ff_geglu320(ops.layernorm(x, gm, bt), pack, b2, want, **kw)
-    ops.ff_geglu320(x, pack_ln, b2, got, ln_folded=True, **kw)
-    rows = torch.randperm(M, generator=_g(4))[:4096].to(DEV)
-    xs = (x.hi if isinstance(x, ops.Res) else x)[rows].float()                 # the folded path sees the hi plane
-    n = F.layer_norm(xs, (C,), gm.float(), bt.float(), 1e-5)
-    pre = n @ w1.float().t() + b1.float()
-    ff = (pre[:, :1280] * F.gelu(pre[:, 1280:])) @ w2.float().t() + b2.float()
-    ref = ff + h.float()[rows] if form == "s_ff" else (1 - a) * (ff + hm[rows].float()) + a * h.float()[rows]
-    g_, w_ = got.float(), want.float()
-    e_ref, e_pair = rel_l2(g_[rows].cpu(), ref.cpu()), rel_l2(g_.cpu(), w_.cpu())
-    e_ffonly = rel_l2((g_[rows] - (ref - ff)).cpu(), ff.cpu())
-    print(f"fused feed-forward with FOLDED LayerNorm {form} M={M}: rel-L2 vs fp32 torch {e_ref:.2e} (feed-forward term alone {e_ffonly:.2e}), "
-          f"vs LayerNorm kernel + fused kernel {e_pair:.2e}")
-    assert torch.isfinite(g_).all() and e_ref < 3e-4 and e_pair < 3e-4

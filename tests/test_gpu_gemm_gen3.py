@@ -139,44 +139,125 @@ def test_conv3x3(ops, lib, N, C, c2, O, H, W, stride, up, eps):
     assert rel_l2(g3.float().cpu(), g1.float().cpu()) < 1e-3
 
 
-@pytest.mark.parametrize("N,C,c2,O,H,W", [(50, 64, 0, 320, 24, 128),       # level-0 geometry (W = 128: two image rows per tile), one chunk
-                                         (9, 128, 64, 320, 72, 128),      # dual source, three chunks, 324 tiles: whole-tile rounds + stream-K tail
-                                         (13, 128, 0, 640, 37, 64),       # level-1 geometry (W = 64: four image rows per tile), two tile columns, ragged last row tile
-                                         (8, 64, 0, 320, 25, 256)])       # one image row per tile, fewer tiles than CUs (no stream-K)
-def test_conv3x3_halo_slab_loader(ops, lib, N, C, c2, O, H, W):
-    """Round 5: the halo-slab A loader (gemm3 MODE 3: one slab per (channel chunk, kernel row) serves the three kernel columns; an experiment,
-    off by default: ew_set_gemm_debug bit 4 / EW_G3_HALO=1) for stride-1 convs with row-bias + split output whose tiles are whole image rows --
-    against torch AND bit for bit against the plain per-tap loader (bit 3): same K order, same operand values, same MFMA sequence."""
-    x1, x2 = rnd(N, C, H, W, seed=1), (rnd(N, c2, H, W, seed=7) if c2 else None)
-    w, b = rnd(O, C + c2, 3, 3, seed=2) / math.sqrt(9 * (C + c2)), rnd(O, seed=3)
-    xin = (torch.cat([x1, x2], 1) if c2 else x1).half().float()
-    ref = F.conv2d(xin.to(DEV), w.half().float().to(DEV), b.half().float().to(DEV), padding=1)
-    M = N * H * W
-    rpg = 2 * H * W
-    rb = rnd(M // rpg + 1, O + 32, seed=4).half().to(DEV)
-    a1, a2 = _nhwc(x1), (_nhwc(x2) if c2 else None)
-    wp, bh = _pack3(w), b.half().to(DEV)
-    lib.ew_set_gemm_debug.argtypes = [ctypes.c_int]
+@pytest.mark.parametrize("case", ["dense_r1", "dense_rb_r1_r2", "dense_shortk_r1", "conv_r1", "convt_rb_r1"])
+@pytest.mark.parametrize("streamk", [False, True])
+def test_reslds_epilogue_matches_register_operand_build(ops, lib, case, streamk):
+    """generation 3's residual-carrying direct epilogues (<*, 18 / 19 / 22 / 23>) land their r1 / r2 tiles in LDS by LDS-DMA behind COUNTED
+    s_waitcnt vmcnt(n) waits whose counts assume how many global_store / DMA instructions hipcc emits per fragment -- wrong output with no error if a
+    compiler update ever emits fewer.  This test runs every such variant on problems with full AND edge tiles (ragged M), with and without the
+    stream-K tail, through the shipped library and through a build of the same source with the pre-round-5 register-operand epilogue
+    (-DEW_G3_RESLDS=0: `make -C evoworld_amd/csrc reslds0`, built by __graft_entry__.build()) and requires the two to agree BIT FOR BIT (to the last fp32 bit where scaling coefficients make the fma contraction order differ)."""
+    import os
+    from evoworld_amd import _lib
+    alt_path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libevoworld_hip_reslds0.so")
+    if not os.path.exists(alt_path):
+        pytest.fail(f"{alt_path} missing: run `make -C evoworld_amd/csrc reslds0` (or __graft_entry__.build())")
+    alt = ctypes.CDLL(alt_path)
+    alt.ew_gemm_f16.argtypes, alt.ew_gemm_f16.restype = [ctypes.POINTER(_lib.GemmArgs), ctypes.c_void_p], ctypes.c_int
+    alt.ew_last_error.restype = ctypes.c_char_p
+    alt.ew_gemm_last_kernel.restype = ctypes.c_char_p
+    alt.ew_set_gemm_debug.argtypes = [ctypes.c_int]
+    alt.ew_gemm_streamk_init.argtypes, alt.ew_gemm_streamk_init.restype = [ctypes.c_void_p], ctypes.c_int
+    alt.ew_gemm_streamk_status.restype = ctypes.c_int
+    g = torch.Generator().manual_seed(17)
+    r = lambda *sh: (torch.rand(*sh, generator=g) * 2 - 1)
+    kw = {}
+    if case.startswith("dense"):
+        M, N, K = {"dense_r1": (115200 + 77, 640, 2560), "dense_rb_r1_r2": (57600 + 130, 1280, 1280), "dense_shortk_r1": (115200 + 9, 640, 640)}[case]
+        a, w = r(M, K).half().to(DEV), (r(N, K) / math.sqrt(K)).half().to(DEV)
+        kw = dict(M=M, N=N, c1=K, lda=K)
+        if case == "dense_rb_r1_r2":
+            kw.update(rowbias=r(M // 5000 + 1, N).half().to(DEV), rows_per_group=5000, ld_rowbias=N, r2=ops.Res.from_float(r(M, N).to(DEV)), ld_r2=N, c_r2=0.4, c_acc=0.6)
+        want = {"dense_r1": "<0, 19>", "dense_rb_r1_r2": "<0, 23>", "dense_shortk_r1": "<0, 19>"}[case]
+    elif case == "conv_r1":
+        Nimg, C, O, H, W = 19, 128, 640, 36, 64
+        M, N = Nimg * H * W, O
+        a = r(M, C).half().to(DEV)
+        w = ops.pack_conv_weight((r(O, C, 3, 3) / math.sqrt(9 * C)).to(DEV))
+        kw = dict(M=M, N=N, c1=C, lda=C, mode=ops.A_CONV3X3, conv=(Nimg, H, W, H, W, 1, 0))
+        want = "<1, 18>"
+    else:
+        B, T, P, C, O = 2, 25, 2304 + 3, 128, 640
+        M, N = B * T * P, O
+        a = r(M, C).half().to(DEV)
+        w = ops.pack_conv_weight((r(O, C, 3, 1, 1) / math.sqrt(3 * C)).to(DEV))
+        kw = dict(M=M, N=N, c1=C, lda=C, mode=ops.A_CONVT3, tconv=(B, T, P), rowbias=r(B, N).half().to(DEV), rows_per_group=T * P, ld_rowbias=N)
+        want = "<2, 19>"
+    bias = r(N).half().to(DEV)
+    r1 = ops.Res.from_float(r(M, N).to(DEV) * 2)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ops.streamk_init()
+    assert alt.ew_gemm_streamk_init(st) == 0
 
-    def run(dbg):
-        out = ops.Res.empty(M, O, DEV, True)
-        out.hi.fill_(7.0); out.lo.fill_(3)
-        lib.ew_set_gemm_debug(dbg)
+    def run(L):
+        out = ops.Res.empty(M, N, DEV, True)
+        out.hi.fill_(5.0); out.lo.fill_(1)
+        L.ew_set_gemm_debug(0 if streamk else 4)
+        keep = _lib._lib
+        _lib._lib = L                                    # ops.gemm fills the ew_gemm_args struct; the call goes to library L
         try:
-            ops.gemm(a1, wp, out, M=M, N=O, c1=C, lda=C, a2=a2, c2=c2, lda2=c2, bias=bh, rowbias=rb, ld_rowbias=O + 32,
-                     rows_per_group=rpg, mode=ops.A_CONV3X3, conv=(N, H, W, H, W, 1, 0))
-            name = lib.ew_gemm_last_kernel().decode()
+            ops.gemm(a, w, out, bias=bias, r1=r1, ld_r1=N, **kw)
+            name = L.ew_gemm_last_kernel().decode()
         finally:
-            lib.ew_set_gemm_debug(0)
+            _lib._lib = keep
+            L.ew_set_gemm_debug(0)
         torch.cuda.synchronize()
         return out, name
-    halo, kh = run(16)
-    plain, kp = run(8)
-    assert kh == "gemm3_kernel<3, 17>" and kp == "gemm3_kernel<1, 17>", (kh, kp)
-    assert torch.equal(halo.hi, plain.hi) and torch.equal(halo.lo, plain.lo)
-    y = ref.permute(0, 2, 3, 1).reshape(M, O) + rb.float()[torch.arange(M, device=DEV) // rpg, :O]
-    assert rel_l2(halo.float().cpu(), y.cpu()) < 3e-4
-    ops.streamk_check()
+    lib.ew_set_gemm_debug.argtypes = [ctypes.c_int]
+    o1, n1 = run(lib)
+    o0, n0 = run(alt)
+    assert n1 == n0 == "gemm3_kernel" + want, (n1, n0)
+    assert lib.ew_gemm_streamk_status() == 0 and alt.ew_gemm_streamk_status() == 0
+    f1, f0 = o1.float(), o0.float()
+    nbad = int((o1.hi != o0.hi).sum()) + int((o1.lo != o0.lo).sum())
+    dmax = float((f1 - f0).abs().max())
+    print(f"RES_LDS 1 vs 0, {case}, stream-K {streamk}: {nbad} differing hi / lo8 words of {2 * M * N}, max |delta| of the decoded values {dmax:.2e}")
+    assert torch.isfinite(f1).all() and float(f1.abs().mean()) > 0.1
+    if "r2" in case:
+        # c_acc / c_r2 != 1: the two epilogues contract acc * c_acc + r1 + c_r2 * r2 into fmas in a different order -- last-bit differences of the fp32
+        # value (one lo8 step = 2^-18 relative) are legitimate; a stale LDS tile would be wrong by O(1) on whole 16-row fragments
+        assert dmax < 4e-5 and nbad < 0.02 * M * N
+    else:
+        assert nbad == 0
+
+
+@pytest.mark.parametrize("N,C,c2,O,H,W,split_rows", [(7, 64, 0, 4, 24, 40, False),        # ragged last workgroup (6720 pixels)
+                                                     (5, 128, 64, 4, 36, 64, True),        # conv_out's form: rows [x_hi | x_lo] + the x_hi half again (lda2 != c2)
+                                                     (3, 192, 0, 8, 40, 48, False), (2, 64, 64, 16, 72, 128, False)])
+def test_conv3x3_small_n_kernel(ops, lib, N, C, c2, O, H, W, split_rows):
+    """Round 6: stride-1 3x3 convs with N <= 16 output channels (the U-Net's conv_out: 320 -> 4 with three split-operand K blocks) run on
+    conv_small_n_kernel instead of a 160-wide tile of the generic kernels -- against torch and against generation 1."""
+    M = N * H * W
+    if split_rows:
+        xs = rnd(N, C, H, W, seed=1)                                     # source 1 = the full 2*c2-wide rows, source 2 = their first c2 channels
+        a1 = _nhwc(xs)
+        a2, lda2 = a1, C
+        xin = torch.cat([xs, xs[:, :c2]], 1)
+    else:
+        x1, x2 = rnd(N, C, H, W, seed=1), (rnd(N, c2, H, W, seed=7) if c2 else None)
+        a1, a2, lda2 = _nhwc(x1), (_nhwc(x2) if c2 else None), c2
+        xin = torch.cat([x1, x2], 1) if c2 else x1
+    w, b = rnd(O, C + c2, 3, 3, seed=2) / math.sqrt(9 * (C + c2)), rnd(O, seed=3)
+    ref = F.conv2d(xin.half().float().to(DEV), w.half().float().to(DEV), b.half().float().to(DEV), padding=1)
+    wp, bh = _pack3(w), b.half().to(DEV)
+    out = torch.empty(M, O, dtype=torch.float16, device=DEV)
+
+    def run():
+        out.fill_(9.0)
+        return ops.gemm(a1, wp, out, M=M, N=O, c1=C, lda=C, a2=a2, c2=c2, lda2=lda2, bias=bh, mode=ops.A_CONV3X3, conv=(N, H, W, H, W, 1, 0))
+    lib.ew_set_gemm_generation(3)
+    g3 = run().clone()
+    assert lib.ew_gemm_last_kernel().decode() == f"conv_small_n_kernel<{(O + 3) // 4 * 4}>", lib.ew_gemm_last_kernel()
+    lib.ew_set_gemm_generation(1)
+    try:
+        g1 = run().clone()
+        assert lib.ew_gemm_last_kernel().decode().startswith("gemm_kernel")
+    finally:
+        lib.ew_set_gemm_generation(3)
+    y = ref.permute(0, 2, 3, 1).reshape(M, O)
+    e, e1 = rel_l2(g3.float().cpu(), y.cpu()), rel_l2(g3.float().cpu(), g1.float().cpu())
+    print(f"conv3x3 small-N O={O}: rel-L2 vs torch {e:.2e}, vs generation 1 {e1:.2e}")
+    assert e < 4e-4 and e1 < 4e-4
 
 
 def test_conv_temporal(ops, lib):

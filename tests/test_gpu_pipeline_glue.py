@@ -79,7 +79,8 @@ def test_pipeline_call_vs_reference_run(gold, hip_unet, tag):
     assert abs(seen[0]["t"] - float(gold[f"{tag}_step0_timestep"])) < 1e-5
     e2 = torch.from_numpy(gold[f"{tag}_image_embeddings"])
     assert float(seen[0]["ehs"][0].abs().max()) == 0.0
-    e_clip = rel_l2(seen[0]["ehs"][1].float().cpu(), e2[1])
+    # (round 6: the pipeline hands the forward the embeddings already on the fp16 grid the forward always converted them to: compare on that grid)
+    e_clip = rel_l2(seen[0]["ehs"][1].float().cpu(), e2[1].half().float())
     print(f"[{tag}] image embeddings (HIP antialias resize + normalisation -> stand-in CLIP) {e_clip:.2e}")
     assert e_clip < 1e-4
     assert np.array_equal(seen[0]["ids"].float().cpu().numpy(), gold[f"{tag}_added_time_ids"])

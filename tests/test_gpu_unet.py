@@ -117,18 +117,17 @@ def test_unet_split_operands_buy_parity(seed, monkeypatch):
     assert res[(False, "1")][0] ** 2 < 0.92 * res[(False, "0")][0] ** 2 and res[(False, "2")][0] < TOL_FORWARD_FP32_WEIGHTS
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1])
 def test_unet_level0_320_fused_feed_forward_modes(mode, monkeypatch):
     """A shrunken config whose FIRST level has the real 320 channels (head_dim 64, hidden 1280), so that its three feed-forwards go through
-    ew_ff_geglu320_f16: mode 0 = LayerNorm + two GEMMs, 1 = LayerNorm kernel + fused kernel (default), 2 = LayerNorm in the fused kernel's
-    prologue, 3 = norm3 folded into the up-projection of .ff (hi plane normalised in registers).  Every mode is checked against the fp32 oracle at the
-    forward tolerance."""
+    ew_ff_geglu320_f16: mode 0 = LayerNorm + two GEMMs (the A/B baseline), 1 = LayerNorm kernel + fused kernel (default).  Both are checked
+    against the fp32 oracle at the forward tolerance."""
     from oracle.unet_ref import tiny_config
     cfg = tiny_config()
     cfg["block_out_channels"] = (320, 128, 256, 256)
     cfg["num_attention_heads"] = (5, 2, 4, 4)
     B, T, h, w = 2, 4, 16, 32
-    monkeypatch.setenv("EW_FUSED_FF", str(mode))     # read at construction: the folded-LayerNorm packs of mode 3 are only built when it is selected
+    monkeypatch.setenv("EW_FUSED_FF", str(mode))     # read at construction
     m, ref, x, ehs, ids = _setup(cfg, B, T, h, w, seed=11)
     assert m.fused_ff == mode
     t = torch.tensor(0.9)
