@@ -4,7 +4,7 @@
 # graphics clock domain while the GPU is busy, so the ratio is the clock the kernel actually ran at under the power limit (DVFS).
 # Writes gpurun_out/<tag>_clock.json + prints a table.   Usage on the GPU box: bash tools/pmc_clock.sh [tag]
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r05}
+TAG=${1:-r06}
 mkdir -p $REPO/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_c
