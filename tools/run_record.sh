@@ -21,6 +21,7 @@ rm -rf /tmp/prof_f
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_f -- python $R/bench.py --steps 1 --warmup 0 --denoise-steps 2 --no-cpu-baseline --no-fp16-stream > /tmp/prof_f.log 2>&1
 f=$(find /tmp/prof_f -name "*kernel_trace.csv" | head -1)
 python $R/tools/csv_kernel_stats.py $f 3 > $R/gpurun_out/${T}_three_forwards_kernel_stats.md
+python $R/tools/steady_state_forward.py $f > $R/gpurun_out/${T}_steady_state_forward.md 2>&1; head -6 $R/gpurun_out/${T}_steady_state_forward.md
 s=$(find /tmp/prof_f -name "*kernel_stats.csv" | head -1)
 [ -n "$s" ] && head -40 $s > $R/gpurun_out/${T}_rocprofv3_kernel_stats.csv
 head -12 $R/gpurun_out/${T}_three_forwards_kernel_stats.md
