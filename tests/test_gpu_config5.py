@@ -107,3 +107,57 @@ def test_full_width_unet_T49_at_128x256_latents_properties():
     print(f"config-5 FULL WIDTH: default vs generation-1 GEMMs rel-L2 {e2:.2e}")
     assert e2 < 3e-3
     del b, one
+
+
+def test_unet_T49_forward_vs_oracle_fp32_weights():
+    """configs[4]'s frame count against the fp32 CPU oracle (which cannot run the 128x256 size: hours): tiny U-Net, T = 49 (temporal attention on the
+    64-frame kernel, 49-frame GroupNorm slabs, time_pos_embed over 49 positions), B = 2, 32x64 latents, the reference's weight protocol (fp32
+    checkpoint kept by the oracle, packed to fp16 by the HIP loader).  One forward at the north_star's 1e-3."""
+    from evoworld_amd.unet import DEFAULT_CONFIG, UNetSpatioTemporalConditionModel, random_state_dict
+    from oracle.unet_ref import UNetSpatioTemporalConditionModelRef, tiny_config
+    cfg = tiny_config()
+    cfg["num_frames"] = 49
+    sd = random_state_dict({**DEFAULT_CONFIG, **cfg}, 5)
+    ref = UNetSpatioTemporalConditionModelRef(**cfg).eval()
+    ref.load_state_dict(sd, strict=True)
+    m = UNetSpatioTemporalConditionModel(**cfg).load_state_dict(sd, device=DEV)
+    B, T, h, w = 2, 49, 32, 64
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, T, 18, h, w, generator=g)
+    ehs = torch.randn(B, 1, cfg["cross_attention_dim"], generator=g)
+    ehs[0] = 0
+    ids = torch.tensor([[6.0, 127.0, 0.02]] * B)
+    t = torch.tensor(0.8)
+    with torch.no_grad():
+        want = ref(x, t, ehs, ids)
+    got = m(x.to(DEV), t, ehs.to(DEV), ids.to(DEV), return_dict=False)[0]
+    e = rel_l2(got.cpu(), want)
+    print(f"config-5 frame count: tiny U-Net, T = 49, 32x64 latents, fp32 checkpoint: forward rel-L2 vs CPU oracle {e:.3e}")
+    assert torch.isfinite(got).all() and e < 1.0e-3
+
+
+def test_pipeline_50_steps_T49_vs_oracle():
+    """configs[4]'s schedule -- 50 EulerDiscrete steps, 49 frames -- through the pipeline on the tiny U-Net against the fp32 oracle loop (16x32
+    latents): the clip the pipeline returns at the north_star's 1e-3."""
+    from evoworld_amd.pipeline import StableVideoDiffusionPipeline
+    from evoworld_amd.unet import DEFAULT_CONFIG, UNetSpatioTemporalConditionModel, random_state_dict
+    from oracle.pipeline_ref import oracle_loop
+    from oracle.unet_ref import UNetSpatioTemporalConditionModelRef, tiny_config
+    cfg = tiny_config()
+    cfg["num_frames"] = 49
+    sd = random_state_dict({**DEFAULT_CONFIG, **cfg}, 5)
+    ref = UNetSpatioTemporalConditionModelRef(**cfg).eval()
+    ref.load_state_dict(sd, strict=True)
+    unet = UNetSpatioTemporalConditionModel(**cfg).load_state_dict(sd, device=DEV)
+    pipe = StableVideoDiffusionPipeline(unet=unet)
+    T, h, w, steps = 49, 16, 32, 50
+    g = torch.Generator().manual_seed(2)
+    lat0, il = torch.randn(1, T, 4, h, w, generator=g), torch.randn(1, T + 1, 4, h, w, generator=g)
+    ehs, pl = torch.randn(1, 1, cfg["cross_attention_dim"], generator=g), torch.randn(1, T, 6, h, w, generator=g)
+    out = pipe(torch.zeros(1, 3, h * 8, w * 8), height=h * 8, width=w * 8, num_frames=T, num_inference_steps=steps, latents=lat0,
+               output_type="latent", plucker_embedding=pl, image_latents=il, image_embeddings=ehs).frames
+    with torch.no_grad():
+        want = oracle_loop(ref, lat0, il, ehs, pl, T, steps)
+    e = rel_l2(out.cpu(), want)
+    print(f"config-5 schedule: 50 steps x 49 frames, tiny U-Net, fp32 checkpoint: clip rel-L2 vs CPU oracle loop {e:.3e}")
+    assert torch.isfinite(out).all() and e < 1.0e-3

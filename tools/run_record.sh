@@ -30,5 +30,5 @@ python bench_episode.py > gpurun_out/${T}_bench_episode.json 2> gpurun_out/${T}_
 python bench_reproject.py > gpurun_out/${T}_bench_reproject.json 2> gpurun_out/${T}_bench_reproject.err; tail -c 900 gpurun_out/${T}_bench_reproject.json
 timeout 600 python tools/experiments/exp30_vs_hipblaslt.py > gpurun_out/${T}_vs_hipblaslt.txt 2>&1
 EW_BENCH_FULL_BREAKDOWN=1 EW_BENCH_BY_SHAPE=1 python bench.py --steps 1 --warmup 1 --denoise-steps 4 --no-cpu-baseline --no-fp16-stream > gpurun_out/${T}_bd.json 2> gpurun_out/${T}_bd.txt
-CLK=$(python -c "import json; print(round(json.load(open('gpurun_out/${EW_ROUND}_clock.json'))['overall_ghz'], 3))" 2>/dev/null)
+CLK=$(python -c "import bench; print(round(bench.committed_clock()['ghz'], 3))" 2>/dev/null)     # time-weighted over the launches of >= 300 us (short ones read high)
 python tools/floor_table.py gpurun_out/${T}_bd.txt ${CLK:+--clock $CLK} --vendor gpurun_out/${T}_vs_hipblaslt.txt > gpurun_out/${T}_floor_table.md; tail -12 gpurun_out/${T}_floor_table.md
