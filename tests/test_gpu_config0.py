@@ -105,3 +105,41 @@ def test_config0_single_segment_8_frames_2_steps(tmp_path, golden_dir):
     e = rel_l2(out.cpu(), want)
     print(f"configs[0]: 8 frames, 2 steps, 72x128 latents, case_000 rows 119-126, fp32 checkpoint: clip rel-L2 vs CPU oracle {e:.3e}")
     assert torch.isfinite(out).all() and e < TOL_CLIP2
+
+
+def test_config0_through_the_cli(tmp_path, golden_dir):
+    """The same configuration through the entry point run_single_segment.sh calls: `unified_loop_consistency.py --single_segment --num_frames 8
+    --num_inference_steps 2` on a case_000-shaped episode and a tiny checkpoint in the diffusers folder layout -> 8 frames decoded and saved, the
+    pipeline called with the last 8 poses' Pluecker embedding and a memory cut to the window (the reference's dataset would hand out 25 memory frames
+    for an 8-frame window and fail its channel concat, pipeline_evoworld.py:643)."""
+    import json
+    from safetensors.torch import save_file
+    from evoworld_amd.pipeline import StableVideoDiffusionPipeline
+    from evoworld_amd.unet import DEFAULT_CONFIG, random_state_dict
+    from oracle.unet_ref import tiny_config
+    import unified_loop_consistency as cli
+    g0 = np.load(f"{golden_dir}/config0_plucker.npz")
+    cfg = tiny_config()
+    cfg["num_frames"] = 8
+    ck = tmp_path / "ckpt" / "unet"
+    ck.mkdir(parents=True)
+    json.dump({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, open(ck / "config.json", "w"))
+    save_file({k: v.contiguous() for k, v in random_state_dict({**DEFAULT_CONFIG, **cfg}, 0).items()}, str(ck / "diffusion_pytorch_model.safetensors"))
+    (tmp_path / "data").mkdir()
+    ep, imgs, renders = _episode(tmp_path / "data", golden_dir)
+    seen = {}
+    orig = StableVideoDiffusionPipeline.__call__
+
+    def spy(self, image, **k):
+        seen.update(plucker=k["plucker_embedding"].clone(), memory=k["memorized_pixel_values"].shape, num_frames=k["num_frames"], steps=k["num_inference_steps"])
+        return orig(self, image, **k)
+    StableVideoDiffusionPipeline.__call__ = spy
+    try:
+        rep = cli.main(["--unet_path", str(tmp_path / "ckpt"), "--base_folder", str(ep), "--save_dir", str(tmp_path / "out"), "--num_frames", "8",
+                        "--num_inference_steps", "2", "--save_frames", "--curve_path", "--single_segment"])
+    finally:
+        StableVideoDiffusionPipeline.__call__ = orig
+    assert rep[0]["frames"] == 8 and rep[0]["mode"] == "single_segment"
+    assert seen["num_frames"] == 8 and seen["steps"] == 2 and tuple(seen["memory"]) == (1, 8, 3, 576, 1024)
+    np.testing.assert_allclose(seen["plucker"][0, [0, 3, 7]].cpu().numpy(), g0["plucker_f0_3_7"], atol=3e-6)
+    assert len(os.listdir(tmp_path / "out" / "case_000" / "predictions")) == 8
