@@ -1,0 +1,225 @@
+// gemm4_f16.hip -- generation 4 (round 6): dense GEMM in the shape of the vendor's large-K solutions (profiles/r04_a_hipblaslt_solutions.txt):
+// 256 x 256 x 64 tile, FOUR waves (one per SIMD, the whole 512-register file each), 128 x 128 wave tile = 16 blocks of v_mfma_f32_32x32x16_f16 whose
+// 256 accumulator registers live in AccVGPRs (inline-asm MFMAs with "+a" operands: hipcc keeps builtin MFMA results in arch VGPRs), operands
+// global -> VGPR -> ds_write -> LDS with the global reads TWO K-tiles ahead of their use (128 VGPRs of loads in flight per lane; generation 3's
+// LDS-DMA feed keeps one 72 KB stage in flight per CU, which is what bounds it when A streams from HBM: DESIGN.md 3.3), LDS double-buffered, one
+// barrier per K-tile, a continuous K-tile stream across the output tiles of a persistent workgroup (the next tile's first two K-tiles are in flight
+// while the epilogue runs).
+// Scope: the bias-only / GEGLU dense shapes with N % 256 == 0 (the GEGLU up-projections of levels 1-2: 30 launches, 19.6 ms per forward), plain fp16
+// output.  out = c_acc * act(A W^T + bias), act in {none, GEGLU}.  Reached through ew_gemm_f16 with ew_set_gemm_generation(4) (A/B) -- see DESIGN.md 3.6
+// for what it measured.
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64, NW = 4;
+constexpr int STAGE = (BM + BN) * 128;            // 64 KB: rows 0..255 = A tile (activations), rows 256..511 = W tile, 128 B (64 k) per row
+constexpr int NPIECE = (BM + BN) * 8 / (64 * NW); // 16-byte pieces per thread and K-tile: 16
+
+__device__ __forceinline__ int swz4(int row) { return (row ^ (row >> 3)) & 7; }
+
+#define MFMA_A(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+
+__device__ __forceinline__ void tile_coords4(int id, int tiles_m, int tiles_n, int band, int& tm, int& tn) {
+    if (band <= 0 || tiles_n <= band) { tm = id / tiles_n; tn = id - tm * tiles_n; return; }
+    const int nb = (tiles_n + band - 1) / band;
+    const int per_band = band * tiles_m;
+    const int k = min(id / per_band, nb - 1);
+    const int r = id - k * per_band;
+    const int w = k == nb - 1 ? tiles_n - k * band : band;
+    tm = r / w;
+    tn = k * band + (r - tm * w);
+}
+
+template <int ACT>      // 0: none, 2: GEGLU (value / gate rows interleaved in blocks of 16 by the host pack, as for generation 3)
+__global__ __launch_bounds__(64 * NW, 1) void gemm4_kernel(const GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lq = lane & 31, lh = lane >> 5;
+
+    const int G = gridDim.x;
+    const int total = p.tiles_m * p.tiles_n;
+    const int seq0 = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);      // XCD-contiguous chunks of the tile order
+    const int n_my = seq0 < total ? (total - 1 - seq0) / G + 1 : 0;
+    if (n_my == 0) return;
+    const int nk = p.K / BK;
+    const int V = n_my * nk;                                               // K-tile stream length of this workgroup
+
+    // ---- loader geometry: thread t owns pieces (row t/8 + 32 j, 16-byte slot t & 7), j = 0..15: j < 8 the A tile, j >= 8 the W tile
+    const int prow = tid >> 3, pslot = tid & 7;
+    // W rows are staged permuted so that a lane's 16 accumulators of a 32 x 32 block are consecutive output columns (ACT 0) or the value AND gate of 8
+    // consecutive hidden units (GEGLU): staged row i = 8a + 4h + e  <-  source row 16h + 4a + e  |  16 (a >> 1) + 8h + 4 (a & 1) + e
+    const int pa = prow >> 3, ph = (prow >> 2) & 1, pe = prow & 3;
+    const int wsrc = ACT == 2 ? 16 * (pa >> 1) + 8 * ph + 4 * (pa & 1) + pe : 16 * ph + 4 * pa + pe;
+
+    // per-tile loader state
+    long long a_off[8];                                                    // element offset of A row (tm * 256 + prow + 32 j, clamped) + slot
+    const f16* w_base = p.w;
+    int ld_tile = 0, ld_kt = 0;                                            // stream position of the NEXT load: tile index in my list, K-tile
+    auto loader_new_tile = [&](int ti) __attribute__((always_inline)) {
+        int tm, tn;
+        tile_coords4(seq0 + ti * G, p.tiles_m, p.tiles_n, p.band, tm, tn);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int m = tm * BM + prow + 32 * j;
+            m = m < p.M ? m : p.M - 1;
+            a_off[j] = (long long)m * p.lda + pslot * 8;
+        }
+        w_base = p.w + (size_t)(tn * BN + wsrc) * p.K + pslot * 8;
+    };
+    f16x8 ldr[2][NPIECE];                                                  // two K-tiles of global reads in flight
+    auto issue_loads = [&](auto set_tag) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_tag)::value;
+        if (ld_kt == 0) loader_new_tile(ld_tile);
+        const int k0 = ld_kt * BK;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ldr[SET][j] = *(const f16x8*)(p.a + a_off[j] + k0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ldr[SET][8 + j] = *(const f16x8*)(w_base + (size_t)(32 * j) * p.K + k0);
+        if (++ld_kt == nk) { ld_kt = 0; ++ld_tile; }
+    };
+    auto write_lds = [&](auto set_tag, char* stage) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_tag)::value;
+#pragma unroll
+        for (int j = 0; j < NPIECE; ++j) {
+            const int r = prow + 32 * (j & 7);
+            *(f16x8*)(stage + (j >> 3) * 32768 + r * 128 + ((pslot ^ swz4(r)) << 4)) = ldr[SET][j];
+        }
+    };
+
+    // ---- fragment read offsets: block b (0..3) of the wave's 128 rows, k16 step ks: row = w*128 + b*32 + lq, slot = 2 ks + lh
+    int rd_a[4], rd_w[4];                                                  // per block: row byte offset; the slot term is added per k-step
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        rd_a[b] = (wm * 128 + b * 32 + lq) * 128;
+        rd_w[b] = 32768 + (wn * 128 + b * 32 + lq) * 128;
+    }
+    int sz[4];                                                             // swizzle of row w*128 + b*32 + lq (the same for the A and the W region)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) sz[b] = swz4(b * 32 + lq);
+
+    f32x16 acc[4][4];                                                      // [n block][m block], AccVGPRs
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    zero_acc();
+
+    // ---- prologue: K-tiles 0 and 1 requested, tile 0 stored to stage 0
+    issue_loads(std::integral_constant<int, 0>{});
+    if (V > 1) issue_loads(std::integral_constant<int, 1>{});
+    write_lds(std::integral_constant<int, 0>{}, smem);
+    __syncthreads();
+
+    int cur_tile = 0, cur_kt = 0;
+    auto step = [&](const int v, auto par_tag) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_tag)::value;                      // v & 1: LDS stage of K-tile v; register set PAR holds K-tile v + 2 after this step's loads
+        const char* cur = smem + PAR * STAGE;
+        char* nxt = smem + (PAR ^ 1) * STAGE;
+        if (v + 2 < V) issue_loads(std::integral_constant<int, PAR>{});    // set PAR held K-tile v: stored to LDS during step v - 1
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f16x8 af[4], wf[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                af[b] = *(const f16x8*)(cur + rd_a[b] + (((2 * ks + lh) ^ sz[b]) << 4));
+                wf[b] = *(const f16x8*)(cur + rd_w[b] + (((2 * ks + lh) ^ sz[b]) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) MFMA_A(acc[i][j], wf[i], af[j]);           // D[n][m]
+        }
+        // K-tile v + 1 (requested two steps ago) goes to the other stage: every wave finished reading it at the barrier that ended step v - 1
+        if (v + 1 < V) write_lds(std::integral_constant<int, PAR ^ 1>{}, nxt);
+        if (++cur_kt == nk) {
+            // ---------------- epilogue of output tile cur_tile ----------------
+            int tm, tn;
+            tile_coords4(seq0 + cur_tile * G, p.tiles_m, p.tiles_n, p.band, tm, tn);
+            const int n0 = tn * BN + wn * 128;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // bias of this lane's 16 rows of block i: source rows in the order of the accumulator registers
+                float bv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int a = r >> 2, e = r & 3;
+                    const int n = ACT == 2 ? 16 * (a >> 1) + 8 * lh + 4 * (a & 1) + e : 16 * lh + 4 * a + e;
+                    bv[r] = p.bias ? (float)p.bias[n0 + i * 32 + n] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = tm * BM + wm * 128 + j * 32 + lq;
+                    f32x16 c = acc[i][j];
+                    if constexpr (ACT == 2) {
+                        f16x8 o;
+#pragma unroll
+                        for (int r = 0; r < 8; r += 2) {
+                            const f32x2 val = {c[r] + bv[r], c[r + 1] + bv[r + 1]}, gate = {c[r + 8] + bv[r + 8], c[r + 9] + bv[r + 9]};
+                            const f32x2 y = ew_vgelu2(val, gate) * p.c_acc;
+                            o[r] = (f16)y[0];
+                            o[r + 1] = (f16)y[1];
+                        }
+                        if (m < p.M) *(f16x8*)(p.out + (size_t)m * p.ld_out + ((n0 + i * 32) >> 1) + 8 * lh) = o;
+                    } else {
+                        f16x8 o0, o1;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) { o0[r] = (f16)(p.c_acc * (c[r] + bv[r])); o1[r] = (f16)(p.c_acc * (c[r + 8] + bv[r + 8])); }
+                        if (m < p.M) {
+                            f16* op = p.out + (size_t)m * p.ld_out + n0 + i * 32 + 16 * lh;
+                            *(f16x8*)op = o0;
+                            *(f16x8*)(op + 8) = o1;
+                        }
+                    }
+                }
+            }
+            zero_acc();
+            cur_kt = 0;
+            ++cur_tile;
+        }
+        __syncthreads();
+    };
+    int v = 0;
+    for (; v + 1 < V; v += 2) {
+        step(v, std::integral_constant<int, 0>{});
+        step(v + 1, std::integral_constant<int, 1>{});
+    }
+    if (v < V) step(v, std::integral_constant<int, 0>{});
+}
+
+}  // namespace
+
+extern char g_gemm_last_kernel[64];
+
+bool ew_gemm4_wants(const GemmP& p) {
+    return p.mode == EW_A_DENSE && p.c2 == 0 && p.N % BN == 0 && p.K % BK == 0 && p.K >= 2 * BK && !p.rowbias && !p.r1 && !p.r2 && !p.out_lo &&
+           (p.act == EW_ACT_NONE || p.act == EW_ACT_GEGLU) && p.M >= 2048 && (long long)p.M * p.lda < (1LL << 40);
+}
+
+ew_status ew_gemm4_dispatch(const GemmP& p, hipStream_t s) {
+    GemmP q = p;
+    q.tiles_m = ew_cdiv(p.M, BM);
+    q.tiles_n = p.N / BN;
+    q.band = ((long long)p.N * p.K * 2 > 3LL * 1024 * 1024) ? 4 : 0;
+    const long long tiles = (long long)q.tiles_m * q.tiles_n;
+    int grid = ew_cu_budget();
+    if (tiles < grid) grid = (int)((tiles + 7) / 8 * 8);
+    const int lds = 2 * STAGE;
+    snprintf(g_gemm_last_kernel, 64, "gemm4_kernel<%d>", p.act == EW_ACT_GEGLU ? 2 : 0);
+    if (p.act == EW_ACT_GEGLU) {
+        static std::atomic<unsigned long long> mask{0};
+        if (ew_status st = ew_ensure_dynamic_lds((const void*)gemm4_kernel<2>, lds, mask)) return st;
+        hipLaunchKernelGGL(gemm4_kernel<2>, dim3(grid), dim3(64 * NW), lds, s, q);
+    } else {
+        static std::atomic<unsigned long long> mask{0};
+        if (ew_status st = ew_ensure_dynamic_lds((const void*)gemm4_kernel<0>, lds, mask)) return st;
+        hipLaunchKernelGGL(gemm4_kernel<0>, dim3(grid), dim3(64 * NW), lds, s, q);
+    }
+    return ew_check_launch("ew_gemm_f16(gen4)");
+}
