@@ -6,20 +6,30 @@ and time of that segment and lists every kernel that is not one of this library'
 Usage: python tools/steady_state_forward.py kernel_trace.csv"""
 import collections
 import csv
+import re
 import sys
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"([A-Za-z0-9_:<>, ]+?)\(", name)
+    return (m.group(1) if m else name)[:90]
+
 
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-starts = [i for i, n in enumerate(names) if "sinusoid_kernel" in n and (i == 0 or "sinusoid_kernel" not in names[i - 1])]
+# a forward opens with TWO back-to-back sinusoid launches (timestep, added time ids); the single ones are the cached time_pos_embed of the first forward
+starts = [i for i in range(len(names) - 1) if "sinusoid_kernel" in names[i] and "sinusoid_kernel" in names[i + 1]]
 if len(starts) < 2:
     raise SystemExit(f"need at least two forwards in the trace (found {len(starts)} sinusoid pairs)")
-a, b = starts[-2], starts[-1]
+# with three or more forwards take the step between the SECOND and the THIRD (both inside the denoise loop of one clip: bench.py's per-kernel
+# breakdown forward and its end-of-clip checks come after the last step)
+a, b = (starts[1], starts[2]) if len(starts) >= 3 else (starts[-2], starts[-1])
 seg = rows[a:b]
 agg = collections.OrderedDict()
 for r in seg:
-    k = r["Kernel_Name"]
-    k = k[:k.find("(")] if "(" in k else k
-    t = agg.setdefault(k[:90], [0, 0.0])
+    t = agg.setdefault(short(r["Kernel_Name"]), [0, 0.0])
     t[0] += 1
     t[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 OURS = ("gemm", "conv_small_n", "ff320", "attn_", "gn_", "ln_kernel", "sinusoid", "euler_cfg", "nchw_to_nhwc", "nhwc_to_nchw", "_GLOBAL__N_")
