@@ -9,6 +9,7 @@
 // output.  out = c_acc * act(A W^T + bias), act in {none, GEGLU}.  Reached through ew_gemm_f16 with ew_set_gemm_generation(4) (A/B) -- see DESIGN.md 3.6
 // for what it measured.
 #include "gemm_common.h"
+#include "gemm4_acc.inc"
 
 namespace {
 
@@ -18,7 +19,11 @@ constexpr int NPIECE = (BM + BN) * 8 / (64 * NW); // 16-byte pieces per thread a
 
 __device__ __forceinline__ int swz4(int row) { return (row ^ (row >> 3)) & 7; }
 
-#define MFMA_A(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+// block k = 4 i + j (n block i, m block j) lives in a[16 k : 16 k + 15]
+#define G4_ALL(M, wf, af)                                                                                                                     \
+    M##_0(wf[0], af[0]); M##_1(wf[0], af[1]); M##_2(wf[0], af[2]); M##_3(wf[0], af[3]); M##_4(wf[1], af[0]); M##_5(wf[1], af[1]);              \
+    M##_6(wf[1], af[2]); M##_7(wf[1], af[3]); M##_8(wf[2], af[0]); M##_9(wf[2], af[1]); M##_10(wf[2], af[2]); M##_11(wf[2], af[3]);            \
+    M##_12(wf[3], af[0]); M##_13(wf[3], af[1]); M##_14(wf[3], af[2]); M##_15(wf[3], af[3])
 
 __device__ __forceinline__ void tile_coords4(int id, int tiles_m, int tiles_n, int band, int& tm, int& tn) {
     if (band <= 0 || tiles_n <= band) { tm = id / tiles_n; tn = id - tm * tiles_n; return; }
@@ -100,16 +105,14 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm4_kernel(const GemmP p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) sz[b] = swz4(b * 32 + lq);
 
-    f32x16 acc[4][4];                                                      // [n block][m block], AccVGPRs
-    auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto read_block = [&](const int k, float (&c)[16]) __attribute__((always_inline)) {
+        switch (k) {
+            case 0: G4_READ_0(c); break; case 1: G4_READ_1(c); break; case 2: G4_READ_2(c); break; case 3: G4_READ_3(c); break;
+            case 4: G4_READ_4(c); break; case 5: G4_READ_5(c); break; case 6: G4_READ_6(c); break; case 7: G4_READ_7(c); break;
+            case 8: G4_READ_8(c); break; case 9: G4_READ_9(c); break; case 10: G4_READ_10(c); break; case 11: G4_READ_11(c); break;
+            case 12: G4_READ_12(c); break; case 13: G4_READ_13(c); break; case 14: G4_READ_14(c); break; default: G4_READ_15(c); break;
+        }
     };
-    zero_acc();
 
     // ---- prologue: K-tiles 0 and 1 requested, tile 0 stored to stage 0
     issue_loads(std::integral_constant<int, 0>{});
@@ -117,27 +120,50 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm4_kernel(const GemmP p) {
     write_lds(std::integral_constant<int, 0>{}, smem);
     __syncthreads();
 
+    // fragments: two sets, the reads of k-step s + 1 are issued before the MFMAs of k-step s
+    f16x8 fa[2][4], fw[2][4];
+    auto read_frags = [&](const char* stage, const int ks, auto set_tag) __attribute__((always_inline)) {
+        constexpr int FS = decltype(set_tag)::value;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            fa[FS][b] = *(const f16x8*)(stage + rd_a[b] + (((2 * ks + lh) ^ sz[b]) << 4));
+            fw[FS][b] = *(const f16x8*)(stage + rd_w[b] + (((2 * ks + lh) ^ sz[b]) << 4));
+        }
+    };
+    read_frags(smem, 0, std::integral_constant<int, 0>{});
+
     int cur_tile = 0, cur_kt = 0;
     auto step = [&](const int v, auto par_tag) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;                      // v & 1: LDS stage of K-tile v; register set PAR holds K-tile v + 2 after this step's loads
         const char* cur = smem + PAR * STAGE;
         char* nxt = smem + (PAR ^ 1) * STAGE;
-        if (v + 2 < V) issue_loads(std::integral_constant<int, PAR>{});    // set PAR held K-tile v: stored to LDS during step v - 1
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            f16x8 af[4], wf[4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                af[b] = *(const f16x8*)(cur + rd_a[b] + (((2 * ks + lh) ^ sz[b]) << 4));
-                wf[b] = *(const f16x8*)(cur + rd_w[b] + (((2 * ks + lh) ^ sz[b]) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) MFMA_A(acc[i][j], wf[i], af[j]);           // D[n][m]
-        }
-        // K-tile v + 1 (requested two steps ago) goes to the other stage: every wave finished reading it at the barrier that ended step v - 1
-        if (v + 1 < V) write_lds(std::integral_constant<int, PAR ^ 1>{}, nxt);
+        auto wr = [&](const int j) __attribute__((always_inline)) {        // piece j of K-tile v + 1 (register set PAR ^ 1) -> the other stage
+            const int r = prow + 32 * (j & 7);
+            *(f16x8*)(nxt + (j >> 3) * 32768 + r * 128 + ((pslot ^ swz4(r)) << 4)) = ldr[PAR ^ 1][j];
+        };
+        const bool more = v + 1 < V;
+        // ---- k-step 0: global reads of K-tile v + 2 (set PAR held K-tile v: in LDS since step v - 1), fragments of k-step 1
+        if (v + 2 < V) issue_loads(std::integral_constant<int, PAR>{});
+        read_frags(cur, 1, std::integral_constant<int, 1>{});
+        if (cur_kt == 0) { G4_ALL(G4_MFMA0, fw[0], fa[0]); }               // first k-step of an output tile: C = 0
+        else { G4_ALL(G4_MFMA, fw[0], fa[0]); }
+        // ---- k-step 1 (+ pieces 0..7 of K-tile v + 1 into the other stage: every wave finished reading it before the barrier of step v - 1)
+        read_frags(cur, 2, std::integral_constant<int, 0>{});
+        G4_MFMA_0(fw[1][0], fa[1][0]); G4_MFMA_1(fw[1][0], fa[1][1]); if (more) wr(0); G4_MFMA_2(fw[1][0], fa[1][2]); G4_MFMA_3(fw[1][0], fa[1][3]); if (more) wr(1);
+        G4_MFMA_4(fw[1][1], fa[1][0]); G4_MFMA_5(fw[1][1], fa[1][1]); if (more) wr(2); G4_MFMA_6(fw[1][1], fa[1][2]); G4_MFMA_7(fw[1][1], fa[1][3]); if (more) wr(3);
+        G4_MFMA_8(fw[1][2], fa[1][0]); G4_MFMA_9(fw[1][2], fa[1][1]); if (more) wr(4); G4_MFMA_10(fw[1][2], fa[1][2]); G4_MFMA_11(fw[1][2], fa[1][3]); if (more) wr(5);
+        G4_MFMA_12(fw[1][3], fa[1][0]); G4_MFMA_13(fw[1][3], fa[1][1]); if (more) wr(6); G4_MFMA_14(fw[1][3], fa[1][2]); G4_MFMA_15(fw[1][3], fa[1][3]); if (more) wr(7);
+        // ---- k-step 2 (+ pieces 8..15)
+        read_frags(cur, 3, std::integral_constant<int, 1>{});
+        G4_MFMA_0(fw[0][0], fa[0][0]); G4_MFMA_1(fw[0][0], fa[0][1]); if (more) wr(8); G4_MFMA_2(fw[0][0], fa[0][2]); G4_MFMA_3(fw[0][0], fa[0][3]); if (more) wr(9);
+        G4_MFMA_4(fw[0][1], fa[0][0]); G4_MFMA_5(fw[0][1], fa[0][1]); if (more) wr(10); G4_MFMA_6(fw[0][1], fa[0][2]); G4_MFMA_7(fw[0][1], fa[0][3]); if (more) wr(11);
+        G4_MFMA_8(fw[0][2], fa[0][0]); G4_MFMA_9(fw[0][2], fa[0][1]); if (more) wr(12); G4_MFMA_10(fw[0][2], fa[0][2]); G4_MFMA_11(fw[0][2], fa[0][3]); if (more) wr(13);
+        G4_MFMA_12(fw[0][3], fa[0][0]); G4_MFMA_13(fw[0][3], fa[0][1]); if (more) wr(14); G4_MFMA_14(fw[0][3], fa[0][2]); G4_MFMA_15(fw[0][3], fa[0][3]); if (more) wr(15);
+        // every fragment read of K-tile v has been issued and K-tile v + 1 is stored: publish it, free this stage
+        __syncthreads();
+        // ---- k-step 3, with the first fragments of K-tile v + 1 read underneath
+        if (more) read_frags(nxt, 0, std::integral_constant<int, 0>{});
+        G4_ALL(G4_MFMA, fw[1], fa[1]);
         if (++cur_kt == nk) {
             // ---------------- epilogue of output tile cur_tile ----------------
             int tm, tn;
@@ -156,7 +182,8 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm4_kernel(const GemmP p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int m = tm * BM + wm * 128 + j * 32 + lq;
-                    f32x16 c = acc[i][j];
+                    float c[16];
+                    read_block(4 * i + j, c);
                     if constexpr (ACT == 2) {
                         f16x8 o;
 #pragma unroll
@@ -179,11 +206,9 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm4_kernel(const GemmP p) {
                     }
                 }
             }
-            zero_acc();
             cur_kt = 0;
             ++cur_tile;
         }
-        __syncthreads();
     };
     int v = 0;
     for (; v + 1 < V; v += 2) {
