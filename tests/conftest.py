@@ -11,6 +11,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle runs on torch's CPU kernels, which crawl when every one of a GPU box's 256 host threads joins a small problem (the tiny-config
+    # oracle took 8 minutes instead of 1 in a run that happened to start with the default): cap the pool for the whole session
+    import torch
+    torch.set_num_threads(min(int(os.environ.get("EW_ORACLE_THREADS", "32")), os.cpu_count() or 1))
 
 
 @pytest.fixture(scope="session")

@@ -128,6 +128,7 @@ def test_unet_T49_forward_vs_oracle_fp32_weights():
     ehs[0] = 0
     ids = torch.tensor([[6.0, 127.0, 0.02]] * B)
     t = torch.tensor(0.8)
+    torch.set_num_threads(min(32, __import__("os").cpu_count() or 1))       # (torch's CPU kernels crawl on 256 threads at these sizes)
     with torch.no_grad():
         want = ref(x, t, ehs, ids)
     got = m(x.to(DEV), t, ehs.to(DEV), ids.to(DEV), return_dict=False)[0]
@@ -156,6 +157,7 @@ def test_pipeline_50_steps_T49_vs_oracle():
     ehs, pl = torch.randn(1, 1, cfg["cross_attention_dim"], generator=g), torch.randn(1, T, 6, h, w, generator=g)
     out = pipe(torch.zeros(1, 3, h * 8, w * 8), height=h * 8, width=w * 8, num_frames=T, num_inference_steps=steps, latents=lat0,
                output_type="latent", plucker_embedding=pl, image_latents=il, image_embeddings=ehs).frames
+    torch.set_num_threads(min(32, __import__("os").cpu_count() or 1))
     with torch.no_grad():
         want = oracle_loop(ref, lat0, il, ehs, pl, T, steps)
     e = rel_l2(out.cpu(), want)
