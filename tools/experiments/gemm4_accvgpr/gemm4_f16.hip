@@ -52,46 +52,56 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm4_kernel(const GemmP p) {
     const int nk = p.K / BK;
     const int V = n_my * nk;                                               // K-tile stream length of this workgroup
 
-    // ---- loader geometry: thread t owns pieces (row t/8 + 32 j, 16-byte slot t & 7), j = 0..15: j < 8 the A tile, j >= 8 the W tile
+    // ---- A loader: thread t owns pieces (row t/8 + 32 j, 16-byte slot t & 7), j = 0..7 of the 256 x 64 A tile; global -> VGPR two K-tiles ahead
     const int prow = tid >> 3, pslot = tid & 7;
-    // W rows are staged permuted so that a lane's 16 accumulators of a 32 x 32 block are consecutive output columns (ACT 0) or the value AND gate of 8
-    // consecutive hidden units (GEGLU): staged row i = 8a + 4h + e  <-  source row 16h + 4a + e  |  16 (a >> 1) + 8h + 4 (a & 1) + e
-    const int pa = prow >> 3, ph = (prow >> 2) & 1, pe = prow & 3;
-    const int wsrc = ACT == 2 ? 16 * (pa >> 1) + 8 * ph + 4 * (pa & 1) + pe : 16 * ph + 4 * pa + pe;
-
-    // per-tile loader state
-    long long a_off[8];                                                    // element offset of A row (tm * 256 + prow + 32 j, clamped) + slot
-    const f16* w_base = p.w;
-    int ld_tile = 0, ld_kt = 0;                                            // stream position of the NEXT load: tile index in my list, K-tile
-    auto loader_new_tile = [&](int ti) __attribute__((always_inline)) {
-        int tm, tn;
-        tile_coords4(seq0 + ti * G, p.tiles_m, p.tiles_n, p.band, tm, tn);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            int m = tm * BM + prow + 32 * j;
-            m = m < p.M ? m : p.M - 1;
-            a_off[j] = (long long)m * p.lda + pslot * 8;
-        }
-        w_base = p.w + (size_t)(tn * BN + wsrc) * p.K + pslot * 8;
-    };
-    f16x8 ldr[2][NPIECE];                                                  // two K-tiles of global reads in flight
+    int a_off[8];                                                          // element offset of A row (tm * 256 + prow + 32 j, clamped) + slot (< 2^31: checked by the host)
+    int ld_tile = 0, ld_kt = 0;                                            // stream position of the NEXT A load: tile index in my list, K-tile
+    f16x8 ldr[2][8];
     auto issue_loads = [&](auto set_tag) __attribute__((always_inline)) {
         constexpr int SET = decltype(set_tag)::value;
-        if (ld_kt == 0) loader_new_tile(ld_tile);
-        const int k0 = ld_kt * BK;
+        if (ld_kt == 0) {
+            int tm, tn;
+            tile_coords4(seq0 + ld_tile * G, p.tiles_m, p.tiles_n, p.band, tm, tn);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ldr[SET][j] = *(const f16x8*)(p.a + a_off[j] + k0);
+            for (int j = 0; j < 8; ++j) {
+                int m = tm * BM + prow + 32 * j;
+                m = m < p.M ? m : p.M - 1;
+                a_off[j] = m * p.lda + pslot * 8;
+            }
+        }
+        const f16* ap = p.a + ld_kt * BK;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ldr[SET][8 + j] = *(const f16x8*)(w_base + (size_t)(32 * j) * p.K + k0);
+        for (int j = 0; j < 8; ++j) ldr[SET][j] = *(const f16x8*)(ap + a_off[j]);
         if (++ld_kt == nk) { ld_kt = 0; ++ld_tile; }
     };
-    auto write_lds = [&](auto set_tag, char* stage) __attribute__((always_inline)) {
+    auto write_a = [&](auto set_tag, char* stage) __attribute__((always_inline)) {
         constexpr int SET = decltype(set_tag)::value;
 #pragma unroll
-        for (int j = 0; j < NPIECE; ++j) {
-            const int r = prow + 32 * (j & 7);
-            *(f16x8*)(stage + (j >> 3) * 32768 + r * 128 + ((pslot ^ swz4(r)) << 4)) = ldr[SET][j];
+        for (int j = 0; j < 8; ++j) {
+            const int r = prow + 32 * j;
+            *(f16x8*)(stage + r * 128 + ((pslot ^ swz4(r)) << 4)) = ldr[SET][j];
         }
+    };
+    // ---- W loader: LDS-DMA (the weight slice of a tile column is L2-resident), one K-tile ahead.  Wave w stages the 1 KB pieces q = w + 4 j, j = 0..7:
+    // staged rows i = 8 q + l / 8 = 32 j + (8 w + l / 8), physical slot l & 7 holds logical slot (l & 7) ^ swz4(i), swz4(i) = (l / 8) ^ ((4 j + w) & 7).
+    // W rows are staged permuted so that a lane's 16 accumulators of a 32 x 32 block are consecutive output columns (ACT 0) or the value AND gate of 8
+    // consecutive hidden units (GEGLU): staged row 8a + 4h + e  <-  source row 16h + 4a + e  |  16 (a >> 1) + 8h + 4 (a & 1) + e
+    const int wi = 8 * wave + (lane >> 3);                                 // staged row inside a 32-row group
+    const int wa = wi >> 3, wh = (wi >> 2) & 1, we = wi & 3;
+    const int wsrc = ACT == 2 ? 16 * (wa >> 1) + 8 * wh + 4 * (wa & 1) + we : 16 * wh + 4 * wa + we;
+    const int wslot[2] = {((lane & 7) ^ (lane >> 3) ^ (wave & 7)) * 8, ((lane & 7) ^ (lane >> 3) ^ ((4 + wave) & 7)) * 8};     // element offset of the logical slot, j even / odd
+    const f16* w_base = p.w;
+    int wd_tile = 0, wd_kt = 0;
+    auto issue_w = [&](char* stage) __attribute__((always_inline)) {
+        if (wd_kt == 0) {
+            int tm, tn;
+            tile_coords4(seq0 + wd_tile * G, p.tiles_m, p.tiles_n, p.band, tm, tn);
+            w_base = p.w + (size_t)(tn * BN + wsrc) * p.K;
+        }
+        const f16* wp = w_base + wd_kt * BK;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) glds16(wp + (size_t)(32 * j) * p.K + wslot[j & 1], stage + 32768 + (wave + 4 * j) * 1024);
+        if (++wd_kt == nk) { wd_kt = 0; ++wd_tile; }
     };
 
     // ---- fragment read offsets: block b (0..3) of the wave's 128 rows, k16 step ks: row = w*128 + b*32 + lq, slot = 2 ks + lh
@@ -115,9 +125,11 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm4_kernel(const GemmP p) {
     };
 
     // ---- prologue: K-tiles 0 and 1 requested, tile 0 stored to stage 0
+    issue_w(smem);
     issue_loads(std::integral_constant<int, 0>{});
     if (V > 1) issue_loads(std::integral_constant<int, 1>{});
-    write_lds(std::integral_constant<int, 0>{}, smem);
+    if (V > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // K-tile 0 (DMA + A pieces) has landed
+    write_a(std::integral_constant<int, 0>{}, smem);
     __syncthreads();
 
     // fragments: two sets, the reads of k-step s + 1 are issued before the MFMAs of k-step s
@@ -137,28 +149,29 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm4_kernel(const GemmP p) {
         constexpr int PAR = decltype(par_tag)::value;                      // v & 1: LDS stage of K-tile v; register set PAR holds K-tile v + 2 after this step's loads
         const char* cur = smem + PAR * STAGE;
         char* nxt = smem + (PAR ^ 1) * STAGE;
-        auto wr = [&](const int j) __attribute__((always_inline)) {        // piece j of K-tile v + 1 (register set PAR ^ 1) -> the other stage
-            const int r = prow + 32 * (j & 7);
-            *(f16x8*)(nxt + (j >> 3) * 32768 + r * 128 + ((pslot ^ swz4(r)) << 4)) = ldr[PAR ^ 1][j];
+        auto wr = [&](const int j) __attribute__((always_inline)) {        // A piece j of K-tile v + 1 (register set PAR ^ 1) -> the other stage
+            const int r = prow + 32 * j;
+            *(f16x8*)(nxt + r * 128 + ((pslot ^ swz4(r)) << 4)) = ldr[PAR ^ 1][j];
         };
         const bool more = v + 1 < V;
-        // ---- k-step 0: global reads of K-tile v + 2 (set PAR held K-tile v: in LDS since step v - 1), fragments of k-step 1
+        // ---- k-step 0: W of K-tile v + 1 by DMA into the other stage (free since the barrier of step v - 1), A of K-tile v + 2 into registers
+        // (set PAR held K-tile v: in LDS since step v - 1), fragments of k-step 1
+        if (more) issue_w(nxt);
         if (v + 2 < V) issue_loads(std::integral_constant<int, PAR>{});
         read_frags(cur, 1, std::integral_constant<int, 1>{});
         if (cur_kt == 0) { G4_ALL(G4_MFMA0, fw[0], fa[0]); }               // first k-step of an output tile: C = 0
         else { G4_ALL(G4_MFMA, fw[0], fa[0]); }
-        // ---- k-step 1 (+ pieces 0..7 of K-tile v + 1 into the other stage: every wave finished reading it before the barrier of step v - 1)
+        // ---- k-step 1 (+ the 8 A pieces of K-tile v + 1 into the other stage: every wave finished reading it before the barrier of step v - 1)
         read_frags(cur, 2, std::integral_constant<int, 0>{});
         G4_MFMA_0(fw[1][0], fa[1][0]); G4_MFMA_1(fw[1][0], fa[1][1]); if (more) wr(0); G4_MFMA_2(fw[1][0], fa[1][2]); G4_MFMA_3(fw[1][0], fa[1][3]); if (more) wr(1);
         G4_MFMA_4(fw[1][1], fa[1][0]); G4_MFMA_5(fw[1][1], fa[1][1]); if (more) wr(2); G4_MFMA_6(fw[1][1], fa[1][2]); G4_MFMA_7(fw[1][1], fa[1][3]); if (more) wr(3);
         G4_MFMA_8(fw[1][2], fa[1][0]); G4_MFMA_9(fw[1][2], fa[1][1]); if (more) wr(4); G4_MFMA_10(fw[1][2], fa[1][2]); G4_MFMA_11(fw[1][2], fa[1][3]); if (more) wr(5);
         G4_MFMA_12(fw[1][3], fa[1][0]); G4_MFMA_13(fw[1][3], fa[1][1]); if (more) wr(6); G4_MFMA_14(fw[1][3], fa[1][2]); G4_MFMA_15(fw[1][3], fa[1][3]); if (more) wr(7);
-        // ---- k-step 2 (+ pieces 8..15)
+        // ---- k-step 2
         read_frags(cur, 3, std::integral_constant<int, 1>{});
-        G4_MFMA_0(fw[0][0], fa[0][0]); G4_MFMA_1(fw[0][0], fa[0][1]); if (more) wr(8); G4_MFMA_2(fw[0][0], fa[0][2]); G4_MFMA_3(fw[0][0], fa[0][3]); if (more) wr(9);
-        G4_MFMA_4(fw[0][1], fa[0][0]); G4_MFMA_5(fw[0][1], fa[0][1]); if (more) wr(10); G4_MFMA_6(fw[0][1], fa[0][2]); G4_MFMA_7(fw[0][1], fa[0][3]); if (more) wr(11);
-        G4_MFMA_8(fw[0][2], fa[0][0]); G4_MFMA_9(fw[0][2], fa[0][1]); if (more) wr(12); G4_MFMA_10(fw[0][2], fa[0][2]); G4_MFMA_11(fw[0][2], fa[0][3]); if (more) wr(13);
-        G4_MFMA_12(fw[0][3], fa[0][0]); G4_MFMA_13(fw[0][3], fa[0][1]); if (more) wr(14); G4_MFMA_14(fw[0][3], fa[0][2]); G4_MFMA_15(fw[0][3], fa[0][3]); if (more) wr(15);
+        G4_ALL(G4_MFMA, fw[0], fa[0]);
+        // the W DMA of K-tile v + 1 has landed (it is older than this step's 8 A loads, which may stay in flight)
+        if (v + 2 < V) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // every fragment read of K-tile v has been issued and K-tile v + 1 is stored: publish it, free this stage
         __syncthreads();
         // ---- k-step 3, with the first fragments of K-tile v + 1 read underneath
@@ -171,13 +184,17 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm4_kernel(const GemmP p) {
             const int n0 = tn * BN + wn * 128;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                // bias of this lane's 16 rows of block i: source rows in the order of the accumulator registers
+                // bias of this lane's 16 rows of block i, in the order of the accumulator registers: two 16-byte loads
                 float bv[16];
+                {
+                    f16x8 b0 = {0, 0, 0, 0, 0, 0, 0, 0}, b1 = b0;
+                    if (p.bias) {
+                        const f16* bp = p.bias + n0 + i * 32 + (ACT == 2 ? 8 * lh : 16 * lh);
+                        b0 = *(const f16x8*)bp;                            // ACT 0: columns 16 lh + 0..7  | GEGLU: value rows 8 lh + 0..7
+                        b1 = *(const f16x8*)(bp + (ACT == 2 ? 16 : 8));   //        columns 16 lh + 8..15 |        gate rows 16 + 8 lh + 0..7
+                    }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int a = r >> 2, e = r & 3;
-                    const int n = ACT == 2 ? 16 * (a >> 1) + 8 * lh + 4 * (a & 1) + e : 16 * lh + 4 * a + e;
-                    bv[r] = p.bias ? (float)p.bias[n0 + i * 32 + n] : 0.f;
+                    for (int r = 0; r < 8; ++r) { bv[r] = (float)b0[r]; bv[r + 8] = (float)b1[r]; }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -224,7 +241,7 @@ extern char g_gemm_last_kernel[64];
 
 bool ew_gemm4_wants(const GemmP& p) {
     return p.mode == EW_A_DENSE && p.c2 == 0 && p.N % BN == 0 && p.K % BK == 0 && p.K >= 2 * BK && !p.rowbias && !p.r1 && !p.r2 && !p.out_lo &&
-           (p.act == EW_ACT_NONE || p.act == EW_ACT_GEGLU) && p.M >= 2048 && (long long)p.M * p.lda < (1LL << 40);
+           (p.act == EW_ACT_NONE || p.act == EW_ACT_GEGLU) && p.M >= 2048 && (long long)p.M * p.lda < (1LL << 31);
 }
 
 ew_status ew_gemm4_dispatch(const GemmP& p, hipStream_t s) {
