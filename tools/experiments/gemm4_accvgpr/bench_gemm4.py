@@ -25,6 +25,7 @@ for (M, N, K, act) in ((28800, 10240, 1280, 2), (115200, 5120, 640, 2), (28800, 
         o.fill_(7.0)
         ms = t(lambda: ops.gemm(x, w, o, M=M, N=N, c1=K, lda=K, bias=b, act=act))
         res[gen] = (ms, lib.ew_gemm_last_kernel().decode())
+    d = float((o3.float() - o4.float()).norm() / o3.float().norm())
     # same launches with every A row aliased onto row 0 (lda = 0: A always an L2 hit; results meaningless): what the A stream's HBM latency costs
     al = {}
     for gen in (3, 4):
@@ -32,5 +33,4 @@ for (M, N, K, act) in ((28800, 10240, 1280, 2), (115200, 5120, 640, 2), (28800, 
         al[gen] = t(lambda: ops.gemm(x, w, o4, M=M, N=N, c1=K, lda=0, bias=b, act=act))
     lib.ew_set_gemm_generation(3)
     fl = 2.0 * M * N * K
-    d = float((o3.float() - o4.float()).norm() / o3.float().norm())
     print(f"M={M} N={N} K={K} act={act}: gen3 {res[3][1]} {res[3][0]:.3f} ms {fl / res[3][0] / 1e9:.0f} TF/s | gen4 {res[4][1]} {res[4][0]:.3f} ms {fl / res[4][0] / 1e9:.0f} TF/s | rel-L2 {d:.2e} | A from L2: gen3 {fl / al[3] / 1e9:.0f} gen4 {fl / al[4] / 1e9:.0f} TF/s", flush=True)
