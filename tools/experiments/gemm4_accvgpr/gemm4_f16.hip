@@ -155,10 +155,12 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm4_kernel(const GemmP p) {
     // ---- prologue: K-tiles 0 and 1 requested, tile 0 stored to stage 0
     issue_w(smem);
     issue_loads(std::integral_constant<int, 0>{});
-    if (V > 1) issue_loads(std::integral_constant<int, 1>{});
-    if (V > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // K-tile 0 (DMA + A pieces) has landed
+    if (V > 1) { issue_loads(std::integral_constant<int, 1>{}); issue_w(smem + STAGE); }
+    if (V > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // K-tile 0 (DMA + A pieces) has landed
     write_a(std::integral_constant<int, 0>{}, smem);
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 
     // fragments: two sets, the reads of k-step s + 1 are issued before the MFMAs of k-step s
     f16x8 fa[2][4], fw[2][4];
@@ -188,20 +190,20 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm4_kernel(const GemmP p) {
 #define RDW(FS, st, ks, b) fw[FS][b] = *(const f16x8*)((st) + rd_w[b] + (((2 * (ks) + lh) ^ sz[b]) << 4))
 #define MM(MF, k, i, j, FS) MF##_##k(fw[FS][i], fa[FS][j])
         // ---- k-step 0 (fragment set 0): fragments of k-step 1 -> set 1; W of K-tile v + 1 by DMA into the other stage (free since the barrier of step v - 1)
-        if (more) w_prep();                     // past the last K-tile the pieces below re-fetch the previous addresses into the free stage / a dead register set: no branches in the MFMA stream
-        // One memory instruction behind every MFMA, fragment reads and the other kinds alternating.
+        // One memory instruction behind every MFMA.  Stream order (vmcnt): W(v+1) [k-step 3 of step v-1], A(v+2) [k-step 0], barrier of step v with vmcnt(8).
+        // ---- k-step 0 (set 0): fragments of k-step 1 -> set 1; A of K-tile v + 2 into register set PAR (it held K-tile v: in LDS since step v - 1)
+        if (more2) a_prep();                    // past the last K-tile the pieces re-fetch the previous addresses into a dead register set / the free stage: no branches in the MFMA stream
 #define GRP0(MF)                                                                                                                                  \
-        MM(MF, 0, 0, 0, 0); RDA(1, cur, 1, 0); MM(MF, 1, 0, 1, 0); W_PIECE(nxt, 0); MM(MF, 2, 0, 2, 0); RDA(1, cur, 1, 1); MM(MF, 3, 0, 3, 0); W_PIECE(nxt, 1); \
-        MM(MF, 4, 1, 0, 0); RDA(1, cur, 1, 2); MM(MF, 5, 1, 1, 0); W_PIECE(nxt, 2); MM(MF, 6, 1, 2, 0); RDA(1, cur, 1, 3); MM(MF, 7, 1, 3, 0); W_PIECE(nxt, 3); \
-        MM(MF, 8, 2, 0, 0); RDW(1, cur, 1, 0); MM(MF, 9, 2, 1, 0); W_PIECE(nxt, 4); MM(MF, 10, 2, 2, 0); RDW(1, cur, 1, 1); MM(MF, 11, 2, 3, 0); W_PIECE(nxt, 5); \
-        MM(MF, 12, 3, 0, 0); RDW(1, cur, 1, 2); MM(MF, 13, 3, 1, 0); W_PIECE(nxt, 6); MM(MF, 14, 3, 2, 0); RDW(1, cur, 1, 3); MM(MF, 15, 3, 3, 0); W_PIECE(nxt, 7)
+        MM(MF, 0, 0, 0, 0); RDA(1, cur, 1, 0); MM(MF, 1, 0, 1, 0); A_PIECE(PAR, 0); MM(MF, 2, 0, 2, 0); RDA(1, cur, 1, 1); MM(MF, 3, 0, 3, 0); A_PIECE(PAR, 1); \
+        MM(MF, 4, 1, 0, 0); RDA(1, cur, 1, 2); MM(MF, 5, 1, 1, 0); A_PIECE(PAR, 2); MM(MF, 6, 1, 2, 0); RDA(1, cur, 1, 3); MM(MF, 7, 1, 3, 0); A_PIECE(PAR, 3); \
+        MM(MF, 8, 2, 0, 0); RDW(1, cur, 1, 0); MM(MF, 9, 2, 1, 0); A_PIECE(PAR, 4); MM(MF, 10, 2, 2, 0); RDW(1, cur, 1, 1); MM(MF, 11, 2, 3, 0); A_PIECE(PAR, 5); \
+        MM(MF, 12, 3, 0, 0); RDW(1, cur, 1, 2); MM(MF, 13, 3, 1, 0); A_PIECE(PAR, 6); MM(MF, 14, 3, 2, 0); RDW(1, cur, 1, 3); MM(MF, 15, 3, 3, 0); A_PIECE(PAR, 7)
         if (cur_kt == 0) { GRP0(G4_MFMA0); } else { GRP0(G4_MFMA); }        // first k-step of an output tile: C = 0
-        // ---- k-step 1 (set 1): fragments of k-step 2 -> set 0; A of K-tile v + 2 into register set PAR (it held K-tile v: in LDS since step v - 1)
-        if (more2) a_prep();
-        MM(G4_MFMA, 0, 0, 0, 1); RDA(0, cur, 2, 0); MM(G4_MFMA, 1, 0, 1, 1); A_PIECE(PAR, 0); MM(G4_MFMA, 2, 0, 2, 1); RDA(0, cur, 2, 1); MM(G4_MFMA, 3, 0, 3, 1); A_PIECE(PAR, 1);
-        MM(G4_MFMA, 4, 1, 0, 1); RDA(0, cur, 2, 2); MM(G4_MFMA, 5, 1, 1, 1); A_PIECE(PAR, 2); MM(G4_MFMA, 6, 1, 2, 1); RDA(0, cur, 2, 3); MM(G4_MFMA, 7, 1, 3, 1); A_PIECE(PAR, 3);
-        MM(G4_MFMA, 8, 2, 0, 1); RDW(0, cur, 2, 0); MM(G4_MFMA, 9, 2, 1, 1); A_PIECE(PAR, 4); MM(G4_MFMA, 10, 2, 2, 1); RDW(0, cur, 2, 1); MM(G4_MFMA, 11, 2, 3, 1); A_PIECE(PAR, 5);
-        MM(G4_MFMA, 12, 3, 0, 1); RDW(0, cur, 2, 2); MM(G4_MFMA, 13, 3, 1, 1); A_PIECE(PAR, 6); MM(G4_MFMA, 14, 3, 2, 1); RDW(0, cur, 2, 3); MM(G4_MFMA, 15, 3, 3, 1); A_PIECE(PAR, 7);
+        // ---- k-step 1 (set 1): fragments of k-step 2 -> set 0
+        MM(G4_MFMA, 0, 0, 0, 1); RDA(0, cur, 2, 0); MM(G4_MFMA, 1, 0, 1, 1); MM(G4_MFMA, 2, 0, 2, 1); RDA(0, cur, 2, 1); MM(G4_MFMA, 3, 0, 3, 1);
+        MM(G4_MFMA, 4, 1, 0, 1); RDA(0, cur, 2, 2); MM(G4_MFMA, 5, 1, 1, 1); MM(G4_MFMA, 6, 1, 2, 1); RDA(0, cur, 2, 3); MM(G4_MFMA, 7, 1, 3, 1);
+        MM(G4_MFMA, 8, 2, 0, 1); RDW(0, cur, 2, 0); MM(G4_MFMA, 9, 2, 1, 1); MM(G4_MFMA, 10, 2, 2, 1); RDW(0, cur, 2, 1); MM(G4_MFMA, 11, 2, 3, 1);
+        MM(G4_MFMA, 12, 3, 0, 1); RDW(0, cur, 2, 2); MM(G4_MFMA, 13, 3, 1, 1); MM(G4_MFMA, 14, 3, 2, 1); RDW(0, cur, 2, 3); MM(G4_MFMA, 15, 3, 3, 1);
         // ---- k-step 2 (set 0): fragments of k-step 3 -> set 1; the 8 A pieces of K-tile v + 1 (register set PAR ^ 1) into the other stage
         MM(G4_MFMA, 0, 0, 0, 0); RDA(1, cur, 3, 0); MM(G4_MFMA, 1, 0, 1, 0); wr(0); MM(G4_MFMA, 2, 0, 2, 0); RDA(1, cur, 3, 1); MM(G4_MFMA, 3, 0, 3, 0); wr(1);
         MM(G4_MFMA, 4, 1, 0, 0); RDA(1, cur, 3, 2); MM(G4_MFMA, 5, 1, 1, 0); wr(2); MM(G4_MFMA, 6, 1, 2, 0); RDA(1, cur, 3, 3); MM(G4_MFMA, 7, 1, 3, 0); wr(3);
@@ -213,11 +215,12 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm4_kernel(const GemmP p) {
         asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        // ---- k-step 3 (set 1), with the first fragments of K-tile v + 1 read underneath -> set 0
-        MM(G4_MFMA, 0, 0, 0, 1); RDA(0, nxt, 0, 0); MM(G4_MFMA, 1, 0, 1, 1); MM(G4_MFMA, 2, 0, 2, 1); RDA(0, nxt, 0, 1); MM(G4_MFMA, 3, 0, 3, 1);
-        MM(G4_MFMA, 4, 1, 0, 1); RDA(0, nxt, 0, 2); MM(G4_MFMA, 5, 1, 1, 1); MM(G4_MFMA, 6, 1, 2, 1); RDA(0, nxt, 0, 3); MM(G4_MFMA, 7, 1, 3, 1);
-        MM(G4_MFMA, 8, 2, 0, 1); RDW(0, nxt, 0, 0); MM(G4_MFMA, 9, 2, 1, 1); MM(G4_MFMA, 10, 2, 2, 1); RDW(0, nxt, 0, 1); MM(G4_MFMA, 11, 2, 3, 1);
-        MM(G4_MFMA, 12, 3, 0, 1); RDW(0, nxt, 0, 2); MM(G4_MFMA, 13, 3, 1, 1); MM(G4_MFMA, 14, 3, 2, 1); RDW(0, nxt, 0, 3); MM(G4_MFMA, 15, 3, 3, 1);
+        // ---- k-step 3 (set 1), with the first fragments of K-tile v + 1 read underneath -> set 0, and W of K-tile v + 2 by DMA into THIS stage (just freed)
+        if (more2) w_prep();
+        MM(G4_MFMA, 0, 0, 0, 1); RDA(0, nxt, 0, 0); MM(G4_MFMA, 1, 0, 1, 1); W_PIECE((char*)cur, 0); MM(G4_MFMA, 2, 0, 2, 1); RDA(0, nxt, 0, 1); MM(G4_MFMA, 3, 0, 3, 1); W_PIECE((char*)cur, 1);
+        MM(G4_MFMA, 4, 1, 0, 1); RDA(0, nxt, 0, 2); MM(G4_MFMA, 5, 1, 1, 1); W_PIECE((char*)cur, 2); MM(G4_MFMA, 6, 1, 2, 1); RDA(0, nxt, 0, 3); MM(G4_MFMA, 7, 1, 3, 1); W_PIECE((char*)cur, 3);
+        MM(G4_MFMA, 8, 2, 0, 1); RDW(0, nxt, 0, 0); MM(G4_MFMA, 9, 2, 1, 1); W_PIECE((char*)cur, 4); MM(G4_MFMA, 10, 2, 2, 1); RDW(0, nxt, 0, 1); MM(G4_MFMA, 11, 2, 3, 1); W_PIECE((char*)cur, 5);
+        MM(G4_MFMA, 12, 3, 0, 1); RDW(0, nxt, 0, 2); MM(G4_MFMA, 13, 3, 1, 1); W_PIECE((char*)cur, 6); MM(G4_MFMA, 14, 3, 2, 1); RDW(0, nxt, 0, 3); MM(G4_MFMA, 15, 3, 3, 1); W_PIECE((char*)cur, 7);
         if (++cur_kt == nk) {
             // ---------------- epilogue of output tile cur_tile ----------------
             int tm, tn;
