@@ -148,9 +148,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     // ---------------- loader state (one K-tile ahead of the MFMA stream, across output tiles) ----------------
     constexpr int NTAP = MODE == EW_A_CONV3X3 ? 9 : (MODE == EW_A_CONVT3 ? 3 : 1);
     int ld_w = 0, ld_kt = 0, ld_k1 = 0, ld_tap = 0, ld_cc = 0;   // ld_kt == ld_k1: the next stage_begin opens work item ld_w
-    int a_ctr[GA];                         // centre-tap pixel (row) index in the source tensors
+    int a_ctr[GA];                         // centre-tap pixel (row) index in the source tensors, relative to the wave's reference pixel a_ref
     int a_mask[GA];                        // bits 0..8 tap validity, bits 16..27 upsample (dy,dx) codes
-    const f16* b_ptr0 = p.w;               // W row of this lane's first piece (+ its 16-byte slot); piece j adds j*NW*8 rows
+    int a_ref = 0;                         // wave-uniform reference pixel: every a_ctr[i] (+ an upsample delta) of this wave is >= 0 relative to it
+    unsigned b_off = 0;                    // byte offset of this lane's W row (first piece) + 16-byte slot inside the tile column's W slice; piece j adds j*NW*8 rows
+    int w_n0 = 0;                          // first W row of the tile column (wave-uniform)
 
     auto loader_new_tile = [&](const int id) __attribute__((always_inline)) {
         int tm, tn;
@@ -208,15 +210,31 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
         int wrow = wave * 8 + srow_o;
         if constexpr (DIRECT)
             wrow = (wave >> 2) * 32 + ((wave >> 1) & 1) * 4 + (2 * (wave & 1) + (srow_o >> 2)) * 8 + (srow_o & 3);
-        b_ptr0 = p.w + (size_t)(n0 + wrow) * p.K + slot_o * 8;                        // N % 320 == 0: every W row exists
+        b_off = (unsigned)((wrow * p.K + slot_o * 8) * 2);                              // N % 320 == 0: every W row exists
+        w_n0 = n0;
+        {
+        // reference pixel of the wave: lane 0 / piece 0 owns the wave's first row, and the source pixel index grows with the row -- except under the
+        // nearest-x2 upsample, where two output rows share a source row (the pixel index falls back by < w_in) and the per-row tap deltas reach w_in + 1 more
+        a_ref = __builtin_amdgcn_readfirstlane(a_ctr[0]);
+        if constexpr (MODE == EW_A_CONV3X3) { if (p.upsample) a_ref -= 2 * p.w_in + 1; }
+#pragma unroll
+        for (int i = 0; i < GA; ++i) a_ctr[i] -= a_ref;
+        }
     };
 
     // staging of one K-tile = stage_begin (wave-uniform source selection, advances the stream counters) + NP DMA pieces
     const f16* st_base = p.a;
-    const f16* st_zp = p.zero_page + slot * 8;
-    long long st_dl = 0;
     int st_tap = 0, st_ld = 0, st_ch = 0;
-    size_t st_koff = 0;
+    // Loader addressing (round 6): the pieces are `buffer_load_dwordx4 ... offen lds`.  One A descriptor per K-tile: base = the wave's reference pixel's
+    // row at this tap / channel chunk (may lie outside the tensor on border tiles: never dereferenced there), a 2 GB window; a lane's offset is
+    // (its pixel - reference) * row bytes + slot -- one v_mad_u32_u24 -- and a padding tap gets an offset outside the window, for which the hardware writes
+    // ZEROS to LDS (tools/experiments/buffer_lds/oob_test.hip): no zero page, no 64-bit pointer arithmetic (v_mad_i64_i32 + 2 v_lshl_add_u64 + a 64-bit
+    // select per piece before) on the VALU, which shares its issue slots with the MFMAs.  W: descriptor = the tile column's K-tile slice, per-lane offset
+    // constant per tile, piece offset in the instruction's SGPR.  VALU instructions per K-tile in the step loop: dense 18 -> 8, 3x3 conv 85 -> 53,
+    // temporal conv 49 -> 26; -1.0 ms per forward in a three-round A/B on one box.
+    __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t st_wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7fffffff, 0x00020000);     // W: K-tile slice of the tile column's rows
+    unsigned st_ld2 = 0;
     char* st_buf = smem;
     auto stage_begin = [&](char* buf) __attribute__((always_inline)) {
         bool opened = false;
@@ -241,8 +259,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
         int dpix = 0;                                                       // wave-uniform tap delta in pixels
         if constexpr (MODE == EW_A_CONV3X3) dpix = (st_tap / 3 - 1) * p.w_in + (st_tap % 3 - 1);
         else if constexpr (MODE == EW_A_CONVT3) dpix = (st_tap - 1) * p.tP;
-        st_dl = (long long)dpix * st_ld + st_ch;
-        st_koff = (size_t)ld_kt * BK;
+        if constexpr (MODE == EW_A_CONV3X3) { if (p.upsample) dpix = 0; }          // per-row deltas instead (stage_piece)
+        const char* ua = (const char*)st_base + ((long long)(a_ref + dpix) * st_ld + st_ch) * 2;
+        st_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ua, 0, 0x7fffffff, 0x00020000);
+        st_ld2 = (unsigned)st_ld * 2u;
+        st_wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.w + ((size_t)w_n0 * p.K + (size_t)ld_kt * BK) * 2), 0, 0x7fffffff, 0x00020000);
         // K order: channel-chunk major, tap minor (the taps of a 64-channel chunk re-hit the same lines in L2 / TCP)
         if (++ld_tap == NTAP) { ld_tap = 0; ld_cc += BK; }
         ++ld_kt;
@@ -250,19 +271,20 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm3_kernel(const GemmP p, const 
     auto stage_piece = [&](int k) __attribute__((always_inline)) {     // k is a compile-time constant after unrolling
         if (k < GA) {
             const int i = k;
-            const f16* src = st_base + ((long long)a_ctr[i] * st_ld + (st_dl + slot * 8));
+            unsigned rel = (unsigned)a_ctr[i];
             if constexpr (MODE == EW_A_CONV3X3) {
                 if (p.upsample) {                                           // per-row deltas (nearest-x2 source coordinates)
                     const int dc = a_mask[i] >> 16;
                     const int dy = ((dc >> (2 * (st_tap / 3))) & 3) - 1, dx = ((dc >> (6 + 2 * (st_tap % 3))) & 3) - 1;
-                    src = st_base + ((long long)(a_ctr[i] + dy * p.w_in + dx) * st_ld + (st_ch + slot * 8));
+                    rel = (unsigned)(a_ctr[i] + dy * p.w_in + dx);
                 }
             }
-            if constexpr (MODE != EW_A_DENSE) src = ((a_mask[i] >> st_tap) & 1) ? src : st_zp;
-            glds16(src, st_buf + (wave + NW * i) * 1024);
+            unsigned voff = __umul24(rel, st_ld2) + (unsigned)(slot * 16);          // < 2^24 pixels and row bytes per tile: one full-rate instruction
+            if constexpr (MODE != EW_A_DENSE) voff = ((a_mask[i] >> st_tap) & 1) ? voff : 0x80000000u;      // padding tap: outside the window -> zeros
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(st_rsrc, (lptr_t)(st_buf + (wave + NW * i) * 1024), 16, (int)voff, 0, 0, 0);
         } else {
-            const int j = k - GA;
-            glds16(b_ptr0 + (size_t)(j * NW * 8) * p.K + st_koff, st_buf + A_BYTES + (wave + NW * j) * 1024);
+            const int j = k - GA;           // piece j = 64 W rows further: the instruction's scalar offset
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(st_wrsrc, (lptr_t)(st_buf + A_BYTES + (wave + NW * j) * 1024), 16, (int)b_off, j * (NW * 8 * 2) * p.K, 0, 0);
         }
     };
 
