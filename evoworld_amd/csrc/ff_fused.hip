@@ -91,6 +91,7 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane16 = (unsigned)(tid & 63) * 16u;
     const int wm = wave >> 1, wn = wave & 1;
     const int frow = lane & 15, fks = lane >> 4, sw = frow & 7;
     if (wave >= NWV / 2) __builtin_amdgcn_s_setprio(1);
@@ -120,10 +121,10 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
 
     // ---- weight DMA stream: global chunk cc <-> W1 / W2 chunk images (cc mod 40), identical for every tile; buffers cc & 1
     auto issue_w1 = [&](int c_mod, int slot) __attribute__((always_inline)) {
-        const f16* s1 = (const f16*)((const char*)p.w1p + (size_t)c_mod * W1_TILE + wave * (P1 * 1024)) + lane * 8;
+        const __amdgpu_buffer_rsrc_t r1d = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.w1p + (size_t)c_mod * W1_TILE), 0, W1_TILE, 0x00020000);
         char* d1 = smem + LDS_W1 + slot * W1_TILE + wave * (P1 * 1024);
 #pragma unroll
-        for (int k = 0; k < P1; ++k) glds16(s1 + k * 512, d1 + k * 1024);
+        for (int k = 0; k < P1; ++k) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1d, (lptr_t)(d1 + k * 1024), 16, (int)lane16, wave * (P1 * 1024) + k * 1024, 0, 0);
     };
     issue_w1(0, 0);
     int cc = 0;                                 // global chunk index
@@ -253,9 +254,10 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
             // DMA requests of this hand-over: W1(cc+2) -> buffer cc & 1 (5 pieces per wave), W2(cc) -> buffer cc & 1 (pieces wave + 8k)
             int c2 = c + 2;
             c2 = c2 >= NCH ? c2 - NCH : c2;
-            const f16* s1 = (const f16*)((const char*)p.w1p + (size_t)c2 * W1_TILE + wave * (P1 * 1024)) + lane * 8;
+            // buffer form (round 6): descriptor = the chunk image, lane offset constant, piece offset scalar -- no 64-bit pointer adds on the VALU
+            const __amdgpu_buffer_rsrc_t r1d = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.w1p + (size_t)c2 * W1_TILE), 0, W1_TILE, 0x00020000);
             char* d1 = smem + LDS_W1 + (cc & 1) * W1_TILE + wave * (P1 * 1024);
-            const f16* s2 = (const f16*)((const char*)p.w2p + (size_t)c * W2_TILE + wave * 1024) + lane * 8;
+            const __amdgpu_buffer_rsrc_t r2d = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.w2p + (size_t)c * W2_TILE), 0, W2_TILE, 0x00020000);
             char* d2 = smem + LDS_W2 + (cc & 1) * W2_TILE + wave * 1024;
             FF_PIN();
             // ---- down-projection of chunk c-1: one k-step x this wave's 10 output fragments x 2 row fragments
@@ -275,8 +277,9 @@ __global__ __launch_bounds__(64 * NWV, NWV / 4) void ff320_kernel(const FfP p) {
                 constexpr int PER = (P1 + P2MAX + 1) / 2;
 #pragma unroll
                 for (int k = g2 * PER; k < g2 * PER + PER && k < P1 + P2MAX; ++k) {
-                    if (k < P1) glds16(s1 + k * 512, d1 + k * 1024);
-                    else if (wave + NWV * (k - P1) < W2_TILE / 1024) glds16(s2 + (k - P1) * NWV * 512, d2 + (k - P1) * NWV * 1024);
+                    if (k < P1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r1d, (lptr_t)(d1 + k * 1024), 16, (int)lane16, wave * (P1 * 1024) + k * 1024, 0, 0);
+                    else if (wave + NWV * (k - P1) < W2_TILE / 1024)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(r2d, (lptr_t)(d2 + (k - P1) * NWV * 1024), 16, (int)lane16, wave * 1024 + (k - P1) * NWV * 1024, 0, 0);
                 }
                 FF_PIN();
             }
